@@ -1,0 +1,55 @@
+# Build of the MI355X (gfx950) render path.
+#
+#   make            -> path_tracer_c_amd/lib/libptgpu.so   (product, C-ABI)
+#                      oracle/liboracle.so                  (test oracle)
+#                      bin/ptrender                         (host C driver)
+#
+# Device code is compiled with -ffp-contract=off: the path's contract is
+# bit-equality with a sequential IEEE-754 binary32 evaluation.
+# Division and square root are correctly rounded (hipcc default, made explicit).
+HIPCC    ?= /opt/rocm/bin/hipcc
+CC       ?= gcc
+ARCH     ?= gfx950
+
+PKG      := path_tracer_c_amd
+CSRC     := $(PKG)/csrc
+BUILD    := build
+LIBDIR   := $(PKG)/lib
+
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off \
+            -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math \
+            -Wall -Wno-unused-function -Iinclude -I$(CSRC)
+CFLAGS   := -std=gnu2x -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude
+
+HOST_OBJS := $(BUILD)/scene.o $(BUILD)/vector.o $(BUILD)/bitmap.o $(BUILD)/scenes.o
+HIP_OBJS  := $(BUILD)/pt_kernels.o $(BUILD)/ptgpu_abi.o
+DEV_HDRS  := $(wildcard $(CSRC)/device/*.h) $(wildcard include/*.h)
+
+all: $(LIBDIR)/libptgpu.so oracle bin/ptrender
+
+$(BUILD) $(LIBDIR) bin:
+	mkdir -p $@
+
+$(BUILD)/%.o: $(CSRC)/host/%.c include/path_tracer_api.h include/ptgpu.h | $(BUILD)
+	$(CC) $(CFLAGS) -c $< -o $@
+
+$(BUILD)/pt_kernels.o: $(CSRC)/device/pt_kernels.hip $(DEV_HDRS) | $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(BUILD)/ptgpu_abi.o: $(CSRC)/ptgpu_abi.hip $(DEV_HDRS) | $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/libptgpu.so: $(HIP_OBJS) $(HOST_OBJS) | $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS) $(HOST_OBJS) -lpthread -lm
+
+bin/ptrender: $(CSRC)/host/main.c $(LIBDIR)/libptgpu.so | bin
+	$(CC) $(CFLAGS) $< -o $@ -L$(LIBDIR) -lptgpu -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -lm -lpthread
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(BUILD) $(LIBDIR) bin
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

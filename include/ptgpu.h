@@ -1,0 +1,160 @@
+/*
+ * ptgpu.h -- explicit C-ABI of the MI355X (gfx950) render path.
+ *
+ * The reference's CPU render path is
+ *     threadpool_add_task(pool, render_task, &args[y]) for every row y
+ *     threadpool_wait_for_tasks(pool)
+ * (include/threadpool.h:15-20, include/renderer.h:6-13; the task body is
+ * src/renderer.c:92-116 calling src/ray.c:4-73).  That surface is kept, see
+ * path_tracer_api.h.  It cannot express samples per pixel, bounce limit, seed
+ * or field of view (compile-time macros in src/renderer.c:6-9) nor device
+ * residency, so this header adds the entry points a binding would use:
+ *
+ *   reference interface replaced            entry point here
+ *   --------------------------------------  ---------------------------------
+ *   scene* argument of render_task          ptgpu_scene_upload / _free
+ *     (include/renderer.h:10)
+ *   one frame of render_task rows           ptgpu_render_frame  (host frame)
+ *     (src/renderer.c:92-116)               ptgpu_render_device (HBM frame)
+ *   the per-pixel sample sum                ptgpu_accumulate_device +
+ *     (src/renderer.c:103-108)              ptgpu_resolve_device (progressive)
+ *   trace_ray (include/ray.h:14-15)         ptgpu_trace_rays (batched)
+ *   NUM_SAMPLES/MAX_BOUNCES/FOV macros      ptgpu_params
+ *     (src/renderer.c:7-9)
+ *
+ * Plain C types only; no exceptions cross the boundary; every function
+ * returns 0 or a negative PTGPU_ERR_* and leaves a message retrievable with
+ * ptgpu_last_error().  There is no CPU fallback anywhere behind this header:
+ * without a usable HIP device every compute call fails with
+ * PTGPU_ERR_NO_DEVICE.
+ */
+#ifndef PTGPU_H
+#define PTGPU_H
+
+#include "path_tracer_api.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTGPU_OK 0
+#define PTGPU_ERR_INVALID (-1)   /* bad argument */
+#define PTGPU_ERR_NO_DEVICE (-2) /* no HIP device / runtime unusable */
+#define PTGPU_ERR_HIP (-3)       /* a HIP call failed; see ptgpu_last_error */
+#define PTGPU_ERR_NOMEM (-4)
+#define PTGPU_ERR_LIMIT (-5)     /* scene or parameters exceed a kernel limit */
+
+/* flags */
+#define PTGPU_FLAG_COMPACT_ROWS 0x1u  /* output row i of the call's row set is
+                                         stored at row i of the destination
+                                         (a shard buffer) instead of at its
+                                         global row (a full frame) */
+#define PTGPU_FLAG_SCENE_GLOBAL 0x2u  /* scan the scene from global memory
+                                         (L2/HBM) instead of the LDS copy */
+#define PTGPU_FLAG_FORCE_TREE 0x4u    /* use the branching (tree) kernel even
+                                         if no material needs it */
+#define PTGPU_FLAG_NO_RAY_COUNT 0x8u  /* skip the ray/sample counters */
+
+/* limits */
+#define PTGPU_MAX_BOUNCES_PATH 62 /* non-branching kernel (LDS material stack) */
+#define PTGPU_MAX_BOUNCES_TREE 14 /* branching kernel (per-lane frame stack) */
+
+typedef struct ptgpu_params {
+    uint32_t spp;           /* samples per pixel rendered by this call
+                               (NUM_SAMPLES, src/renderer.c:9); default 16 */
+    uint32_t max_bounces;   /* MAX_BOUNCES, src/renderer.c:8; default 4.
+                               A non-branching path traces <= max_bounces+1
+                               rays. */
+    float fov_rad;          /* FOV, src/renderer.c:7; default pi/2 */
+    uint32_t seed;          /* stream seed (ptgpu_rng.h); default 1 */
+    uint32_t sample_offset; /* global index of this call's first sample */
+    /* Row set of this call.  Local row i (0 <= i < num_rows) is global row
+     *   row_begin + i                                        (tile_rows == 0)
+     *   row_begin + (i / tile_rows) * tile_rows * tile_stride + i % tile_rows
+     * num_rows == 0 means "every row from row_begin to the bottom". */
+    uint32_t row_begin;
+    uint32_t num_rows;
+    uint32_t tile_rows;
+    uint32_t tile_stride;
+    uint32_t flags;         /* PTGPU_FLAG_* */
+    uint32_t block_threads; /* work-items per workgroup: 0 (= 256), or a
+                               multiple of 64 up to 1024 */
+    uint32_t reserved;
+} ptgpu_params;
+
+typedef struct ptgpu_stats {
+    uint64_t rays;        /* trace_ray-equivalent path segments traced */
+    uint64_t samples;     /* per_pixel-equivalent samples finished */
+    uint64_t wave_iters;  /* sum over wavefronts of bounce-loop iterations */
+    uint64_t launches;    /* megakernel launches */
+} ptgpu_stats;
+
+/* Opaque device-resident scene (geometry + materials in HBM, laid out for the
+ * kernel).  Immutable after upload; belongs to the device current at upload. */
+typedef struct ptgpu_scene ptgpu_scene;
+
+/* -- parameters ------------------------------------------------------------ */
+/* The reference's compile-time settings: 16 spp, 4 bounces, fov pi/2. */
+int ptgpu_params_default(ptgpu_params *p);
+/* Defaults overridden by PTGPU_SPP, PTGPU_BOUNCES, PTGPU_SEED, PTGPU_FOV_DEG,
+ * PTGPU_BLOCK, PTGPU_FLAGS; this is what the legacy entry points use. */
+int ptgpu_params_from_env(ptgpu_params *p);
+
+/* -- devices --------------------------------------------------------------- */
+int ptgpu_device_count(void); /* >= 0, or a negative error */
+int ptgpu_set_device(int device);
+
+/* -- scene residency ------------------------------------------------------- */
+int ptgpu_scene_upload(const scene *host_scene, ptgpu_scene **out);
+void ptgpu_scene_free(ptgpu_scene *s);
+/* 1 if some material has 0 < transparency < 1 (needs the tree kernel). */
+int ptgpu_scene_is_branching(const ptgpu_scene *s);
+
+/* -- rendering ------------------------------------------------------------- */
+/* Asynchronous: renders the row set of `p` of a framew x frameh image into
+ * `d_frame` (device memory, RGB8, 3*framew bytes per row) on `hip_stream`
+ * (a hipStream_t, NULL = default stream).  Bytes written equal, bit for bit,
+ * what the reference's render_task would store for the same stream of random
+ * numbers (src/renderer.c:92-116). */
+int ptgpu_render_device(const ptgpu_scene *s, uint8_t *d_frame, size_t framew,
+                        size_t frameh, const ptgpu_params *p,
+                        void *hip_stream);
+
+/* Synchronous convenience: upload, render, copy the rows back into the
+ * caller's host frame (full-frame addressing), free. */
+int ptgpu_render_frame(const scene *host_scene, uint8_t *frame, size_t framew,
+                       size_t frameh, const ptgpu_params *p);
+
+/* Progressive accumulation.  `d_accum` holds one float4 per pixel of the
+ * destination (sum_r, sum_g, sum_b, samples); zero it before the first pass.
+ * Each call adds p->spp clamped samples per pixel, in sample order, so k
+ * passes of n samples leave exactly the sum one pass of k*n samples leaves. */
+int ptgpu_accumulate_device(const ptgpu_scene *s, float *d_accum,
+                            size_t framew, size_t frameh,
+                            const ptgpu_params *p, void *hip_stream);
+/* frame[i] = (uint8)(sum * (1.0f / samples * 255.0f)) for `npixels` pixels
+ * (src/renderer.c:108-114). */
+int ptgpu_resolve_device(const float *d_accum, uint8_t *d_frame,
+                         size_t npixels, void *hip_stream);
+
+/* -- batched closest-hit queries (host buffers, synchronous) ---------------- */
+/* origins/directions: n x 3 floats; hits: n ray_hit records. */
+int ptgpu_trace_rays(const scene *host_scene, const float *origins,
+                     const float *directions, size_t n, ray_hit *hits);
+
+/* -- bookkeeping ------------------------------------------------------------ */
+int ptgpu_stats_reset(void);
+int ptgpu_stats_read(ptgpu_stats *out); /* synchronises the device */
+const char *ptgpu_last_error(void);     /* thread-local, never NULL */
+const char *ptgpu_version(void);
+
+/* -- synthetic scenes of BASELINE.json's five configurations --------------- */
+/* Fills an initialised-or-not `scene` (scene_init is called inside) with
+ * configuration `config` in 1..5, or 0 for the reference's demo scene
+ * (src/main.c:202-230).  Free with scene_destroy. */
+int ptgpu_build_config_scene(int config, scene *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTGPU_H */

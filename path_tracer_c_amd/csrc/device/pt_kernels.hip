@@ -1,0 +1,577 @@
+// pt_kernels.hip -- the gfx950 megakernel of the render path.
+//
+// One work-item per pixel of the call's row set.  A work-item owns its pixel
+// for the whole launch: it generates the primary ray once (the reference
+// sends the same un-jittered ray for every sample, src/renderer.c:96-100),
+// then runs all `spp` samples of src/renderer.c:103-107 -- each the
+// recursive incident_light of src/renderer.c:21-74 -- adds the clamped
+// samples in sample order, scales, truncates and stores RGB8
+// (src/renderer.c:108-114).  One launch replaces the whole
+// threadpool_add_task/render_task/threadpool_wait_for_tasks frame loop.
+//
+// Shape of the computation on a CU:
+//   * the scene blob (geometry, triangle records, materials, meta) is copied
+//     once per workgroup into LDS; the object scan then reads it with
+//     wave-uniform (broadcast) LDS reads.  Variant: scan it from global
+//     memory (scalar/L2-served loads) for scenes that do not fit LDS and for
+//     the LDS-vs-global comparison of configuration 5.
+//   * incident_light's recursion is unrolled into a forward walk that records
+//     one 16-bit material index per bounce in an LDS stack, and an unwind that
+//     re-applies `Le + lerp(refl, trans, t) * albedo` from the deepest level
+//     up -- the reference's own evaluation order, so results are bit-equal to
+//     a sequential evaluation, which a throughput-product formulation is not.
+//   * path regeneration: a lane whose path ends starts its next sample at
+//     once, so lanes of a wave do not wait for the longest path of each
+//     sample; a wave leaves the loop when its busiest lane is done.  The
+//     ballot of finished lanes is only used for statistics here.
+//   * per-lane xorshift32 in a register, re-seeded per (pixel, sample)
+//     (include/ptgpu_rng.h), three draws per hit like rand_unit_sphere
+//     (src/renderer.c:11-19).
+//   * materials with 0 < transparency < 1 make incident_light a binary tree
+//     (src/renderer.c:45,56,72); scenes that have one run the `kTree`
+//     instantiation, an explicit depth-first walk with a per-lane frame stack.
+//   * RGB8 stores: a wave's 64 pixels are 192 contiguous bytes; lanes 0..47
+//     each assemble one dword with two cross-lane reads and store it.
+//
+// No MFMA: there is no dense contraction anywhere on this path.
+#include "pt_launch.h"
+#include "pt_trace.h"
+#include "pt_vec.h"
+#include "ptgpu_rng.h"
+
+namespace pt {
+
+// Refraction constants of src/renderer.c:58-63, with the reference's types:
+//   float refractive_index = dot < 0 ? 1.5 : 1 / 1.5;     (double -> float)
+//   eta = 1.0 / refractive_index                          (double -> float)
+__device__ constexpr float kIorEnter = (float)1.5;
+__device__ constexpr float kIorLeave = (float)(1 / 1.5);
+__device__ constexpr float kEtaEnter = (float)(1.0 / (double)kIorEnter);
+__device__ constexpr float kEtaLeave = (float)(1.0 / (double)kIorLeave);
+__device__ constexpr float kRayOffset = (float)0.001; // src/renderer.c:49,66
+
+// rand_unit_sphere (src/renderer.c:11-19): normalise a point of the cube
+// [-1,1)^3; three draws in x, y, z order.
+__device__ __forceinline__ V3 rand_unit_sphere(uint32_t &state) {
+    state = ptgpu_xorshift32(state);
+    float rx = ptgpu_u32_to_unit(state);
+    state = ptgpu_xorshift32(state);
+    float ry = ptgpu_u32_to_unit(state);
+    state = ptgpu_xorshift32(state);
+    float rz = ptgpu_u32_to_unit(state);
+    V3 cube = V3{rx, ry, rz} * 2.0f - splat(1.0f);
+    return normalize(cube);
+}
+
+// What one surface interaction decides (src/renderer.c:34-70), given the
+// perturbed normal: the next ray, or that the path has no child at this
+// level (total internal reflection / NaN transparency).
+struct Bounce {
+    V3 origin, direction;
+    bool has_child;
+};
+
+__device__ __forceinline__ Bounce reflect_ray(V3 d, V3 n, V3 point) {
+    Bounce b;
+    b.direction = normalize(reflect(d, n));
+    b.origin = point + b.direction * kRayOffset;
+    b.has_child = true;
+    return b;
+}
+
+__device__ __forceinline__ Bounce refract_ray(V3 d, V3 n, V3 point) {
+    Bounce b;
+    float facing = dot(d, n);
+    float eta = facing < 0.0f ? kEtaEnter : kEtaLeave;
+    V3 rn = facing < 0.0f ? n : -n;
+    V3 bent;
+    b.has_child = refract(d, rn, eta, bent);
+    b.direction = normalize(bent);
+    b.origin = point + b.direction * kRayOffset;
+    return b;
+}
+
+// One level of the unwind: Le + lerp(reflected, transmitted, t) * albedo
+// (src/renderer.c:72-73) where exactly one of the two children is `child`
+// and the other is the zero vector.
+__device__ __forceinline__ V3 shade_level(const F4 m0, const F4 m1, V3 child) {
+    const float t = m1.w;
+    const bool via_reflection = t < 1.0f;
+    V3 refl = via_reflection ? child : splat(0.0f);
+    V3 trans = via_reflection ? splat(0.0f) : child;
+    V3 li = lerp(refl, trans, t);
+    return xyz(m1) + li * xyz(m0);
+}
+
+// ---------------------------------------------------------------------------
+// Non-branching paths: every material has transparency <= 0 or >= 1.
+// ---------------------------------------------------------------------------
+template <class Acc>
+__device__ __forceinline__ void
+run_paths(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
+          uint32_t stack_stride, V3 d0, uint32_t pixel, uint32_t spp, V3 sky,
+          Acc &sum, uint32_t &rays, uint32_t &iters) {
+    uint32_t s = 0;
+    uint32_t depth = 0;
+    V3 o = splat(0.0f);
+    V3 d = d0;
+    uint32_t rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset);
+
+    while (s < spp) {
+        ++iters;
+        ++rays;
+        const Hit h = closest_hit(rec, o, d);
+
+        bool done;
+        V3 r;
+        if (h.distance < 0.0f) { // miss: this level returns the sky colour
+            r = sky;
+            done = true;
+        } else {
+            const Surface sf = surface_at(rec, o, d, h);
+            stack[depth * stack_stride] = (uint16_t)sf.material;
+            ++depth;
+            const F4 m0 = rec.mat[2 * sf.material + 0];
+            const float transparency = rec.mat[2 * sf.material + 1].w;
+
+            V3 deviation = rand_unit_sphere(rng) * m0.w; // roughness * 0.5
+            V3 n = normalize(sf.normal + deviation);
+
+            Bounce b;
+            if (transparency < 1.0f) {
+                b = reflect_ray(d, n, sf.point);
+            } else if (transparency > 0.0f) {
+                b = refract_ray(d, n, sf.point);
+            } else { // NaN transparency: neither branch is taken
+                b.has_child = false;
+                b.origin = o;
+                b.direction = d;
+            }
+            o = b.origin;
+            d = b.direction;
+            r = splat(0.0f);
+            done = !b.has_child;
+            if (!done && depth > a.max_bounces) {
+                // the child call has bounces > MAX_BOUNCES: sky, no trace
+                r = sky;
+                done = true;
+            }
+        }
+
+        if (done) {
+            for (uint32_t k = depth; k-- > 0;) {
+                const uint32_t m = stack[k * stack_stride];
+                r = shade_level(rec.mat[2 * m + 0], rec.mat[2 * m + 1], r);
+            }
+            sum = sum + clamp01(r); // per-sample clamp, src/renderer.c:88
+            ++s;
+            depth = 0;
+            o = splat(0.0f);
+            d = d0;
+            rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset + s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Branching paths: explicit depth-first evaluation of the recursion tree.
+// ---------------------------------------------------------------------------
+constexpr int kTreeFrames = 16; // PTGPU_MAX_BOUNCES_TREE + 2
+
+struct Frame {
+    V3 d_in;   // direction of the ray that hit this surface
+    V3 normal; // perturbed normal
+    V3 point;
+    V3 refl;   // reflected_Li once known
+    uint32_t material;
+    uint32_t awaiting_transmit; // 0: child in flight is the reflection
+};
+
+template <class Acc>
+__device__ void run_tree(const SceneRecords &rec, const LaunchArgs &a, V3 d0,
+                         uint32_t pixel, uint32_t spp, V3 sky, Acc &sum,
+                         uint32_t &rays, uint32_t &iters) {
+    Frame frames[kTreeFrames];
+    for (uint32_t s = 0; s < spp; ++s) {
+        uint32_t rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset + s);
+        int sp = 0; // frames in use; a call at recursion depth k has sp == k
+        V3 o = splat(0.0f), d = d0;
+        V3 ret = splat(0.0f);
+        // state: 0 = enter a call with (o, d, bounces = sp)
+        //        1 = a call returned `ret` to the frame on top
+        //        2 = top frame must now evaluate its transmission branch
+        int state = 0;
+        for (;;) {
+            ++iters;
+            if (state == 0) {
+                if ((uint32_t)sp > a.max_bounces) {
+                    ret = sky;
+                    state = 1;
+                    continue;
+                }
+                ++rays;
+                const Hit h = closest_hit(rec, o, d);
+                if (h.distance < 0.0f) {
+                    ret = sky;
+                    state = 1;
+                    continue;
+                }
+                const Surface sf = surface_at(rec, o, d, h);
+                const F4 m0 = rec.mat[2 * sf.material + 0];
+                const float t = rec.mat[2 * sf.material + 1].w;
+                V3 deviation = rand_unit_sphere(rng) * m0.w;
+                Frame &f = frames[sp];
+                f.d_in = d;
+                f.normal = normalize(sf.normal + deviation);
+                f.point = sf.point;
+                f.refl = splat(0.0f);
+                f.material = sf.material;
+                f.awaiting_transmit = 0;
+                ++sp;
+                if (t < 1.0f) {
+                    Bounce b = reflect_ray(d, f.normal, f.point);
+                    o = b.origin;
+                    d = b.direction;
+                    state = 0;
+                } else {
+                    state = 2;
+                }
+                continue;
+            }
+            if (state == 1) {
+                if (sp == 0)
+                    break; // the root call returned
+                Frame &f = frames[sp - 1];
+                if (!f.awaiting_transmit) {
+                    f.refl = ret;
+                    state = 2;
+                    continue;
+                }
+                // transmitted_Li arrived: finish this level
+                const F4 m0 = rec.mat[2 * f.material + 0];
+                const F4 m1 = rec.mat[2 * f.material + 1];
+                V3 li = lerp(f.refl, ret, m1.w);
+                ret = xyz(m1) + li * xyz(m0);
+                --sp;
+                continue; // state stays 1: return to the parent
+            }
+            // state == 2
+            {
+                Frame &f = frames[sp - 1];
+                const F4 m0 = rec.mat[2 * f.material + 0];
+                const F4 m1 = rec.mat[2 * f.material + 1];
+                const float t = m1.w;
+                bool has_child = false;
+                if (t > 0.0f) {
+                    Bounce b = refract_ray(f.d_in, f.normal, f.point);
+                    has_child = b.has_child;
+                    if (has_child) {
+                        f.awaiting_transmit = 1;
+                        o = b.origin;
+                        d = b.direction;
+                        state = 0;
+                    }
+                }
+                if (!has_child) {
+                    V3 li = lerp(f.refl, splat(0.0f), t);
+                    ret = xyz(m1) + li * xyz(m0);
+                    --sp;
+                    state = 1;
+                }
+            }
+        }
+        sum = sum + clamp01(ret);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The kernel.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t other = __shfl_xor(v, off, 64);
+        v = other > v ? other : v;
+    }
+    return v;
+}
+
+template <bool kLds, bool kTree>
+__global__ void __launch_bounds__(1024) pt_megakernel(const LaunchArgs a) {
+    extern __shared__ uint4 lds_dyn[]; // 16-byte aligned base
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nthreads = blockDim.x;
+
+    // ---- stage the scene blob into LDS (once per workgroup) ---------------
+    const uint32_t n_obj = a.scene.n_obj;
+    const uint32_t n_tri = a.scene.n_tri;
+    const uint32_t n_mat = a.scene.n_mat;
+    const uint32_t blob16 =
+        (uint32_t)(scene_lds_bytes(n_obj, n_tri, n_mat) / 16u);
+
+    SceneRecords rec;
+    rec.n_obj = n_obj;
+    uint32_t lds_used16 = 0;
+    if (kLds) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.scene.geom);
+        for (uint32_t i = tid; i < blob16; i += nthreads)
+            lds_dyn[i] = src[i];
+        const F4 *base = reinterpret_cast<const F4 *>(lds_dyn);
+        rec.geom = base;
+        rec.tri = base + n_obj;
+        rec.mat = base + n_obj + 3u * n_tri;
+        rec.meta = reinterpret_cast<const uint32_t *>(base + n_obj + 3u * n_tri +
+                                                      2u * n_mat);
+        lds_used16 = blob16;
+    } else {
+        rec.geom = a.scene.geom;
+        rec.tri = a.scene.tri;
+        rec.mat = a.scene.mat;
+        rec.meta = a.scene.meta;
+    }
+    uint16_t *stack = reinterpret_cast<uint16_t *>(lds_dyn + lds_used16) + tid;
+    __syncthreads();
+
+    // ---- which pixel is mine ------------------------------------------------
+    const uint32_t W = a.framew;
+    const uint64_t npix = (uint64_t)a.num_rows * W;
+    const uint64_t j = (uint64_t)blockIdx.x * nthreads + tid;
+    const bool valid = j < npix;
+    const uint32_t lrow = valid ? (uint32_t)(j / W) : 0u;
+    const uint32_t sx = valid ? (uint32_t)(j - (uint64_t)lrow * W) : 0u;
+    uint32_t grow = a.row_begin + lrow;
+    if (a.tile_rows != 0u) {
+        const uint32_t tile = lrow / a.tile_rows;
+        grow = a.row_begin + tile * a.tile_rows * a.tile_stride +
+               (lrow - tile * a.tile_rows);
+    }
+    const uint32_t pixel = grow * W + sx; // global pixel index: RNG + ray
+    const uint64_t out_pixel = (uint64_t)(a.compact ? lrow : grow) * W + sx;
+
+    // ---- primary ray (src/renderer.c:94-100, 76-85) --------------------------
+    const float fw = (float)a.framew, fh = (float)a.frameh;
+    const float aspect = fw / fh;
+    const float x = (float)sx / fw * 2.0f - 1.0f;
+    const float y = -((float)grow / fh * 2.0f - 1.0f);
+    const V3 d0 = normalize(
+        V3{x * a.tan_half_fov, y * a.tan_half_fov / aspect, 1.0f});
+    const V3 sky = V3{a.scene.sky[0], a.scene.sky[1], a.scene.sky[2]};
+
+    // ---- all samples of this pixel -----------------------------------------
+    V3 sum = splat(0.0f);
+    float had = 0.0f;
+    if (a.accum != nullptr && valid) {
+        const float4 prev = reinterpret_cast<const float4 *>(a.accum)[out_pixel];
+        sum = V3{prev.x, prev.y, prev.z};
+        had = prev.w;
+    }
+    uint32_t rays = 0, iters = 0;
+    const uint32_t spp = valid ? a.spp : 0u;
+    if (kTree)
+        run_tree(rec, a, d0, pixel, spp, sky, sum, rays, iters);
+    else
+        run_paths(rec, a, stack, nthreads, d0, pixel, spp, sky, sum, rays,
+                  iters);
+
+    // ---- write back ------------------------------------------------------------
+    if (a.accum != nullptr) {
+        if (valid)
+            reinterpret_cast<float4 *>(a.accum)[out_pixel] =
+                make_float4(sum.x, sum.y, sum.z, had + (float)a.spp);
+    } else {
+        // result * (1.0f / NUM_SAMPLES * 255.0f), truncated (renderer.c:108-114)
+        const float scale = 1.0f / (float)a.spp * 255.0f;
+        const V3 px = sum * scale;
+        const uint32_t r8 = (uint32_t)(uint8_t)px.x;
+        const uint32_t g8 = (uint32_t)(uint8_t)px.y;
+        const uint32_t b8 = (uint32_t)(uint8_t)px.z;
+        const uint32_t packed = r8 | (g8 << 8) | (b8 << 16);
+
+        const uint32_t lane = tid & 63u;
+        const uint64_t first = __shfl(out_pixel, 0, 64);
+        const bool wave_dense =
+            __all(valid && out_pixel == first + lane) &&
+            ((reinterpret_cast<uintptr_t>(a.frame + 3u * first) & 3u) == 0u);
+        // dword k of the wave's 192 bytes = bytes 4k..4k+3 = tail of pixel
+        // 4k/3 and head of the next one
+        const uint32_t p0 = (4u * lane) / 3u;
+        const uint32_t sh = 8u * (4u * lane - 3u * p0);
+        const uint32_t lo = __shfl(packed, (int)(p0 & 63u), 64);
+        const uint32_t hi = __shfl(packed, (int)((p0 + 1u) & 63u), 64);
+        if (wave_dense) {
+            if (lane < 48u) {
+                const uint64_t both = (uint64_t)lo | ((uint64_t)hi << 24);
+                uint32_t *dst = reinterpret_cast<uint32_t *>(a.frame + 3u * first);
+                dst[lane] = (uint32_t)(both >> sh);
+            }
+        } else if (valid) {
+            uint8_t *dst = a.frame + 3u * out_pixel;
+            dst[0] = (uint8_t)r8;
+            dst[1] = (uint8_t)g8;
+            dst[2] = (uint8_t)b8;
+        }
+    }
+
+    // ---- statistics: one atomic per wave and counter --------------------------
+    if (a.counters != nullptr) {
+        const uint32_t wrays = wave_sum(rays);
+        const uint32_t wsamples = wave_sum(spp);
+        const uint32_t witers = wave_max(iters);
+        if ((tid & 63u) == 0u) {
+            atomicAdd(&a.counters->rays, (unsigned long long)wrays);
+            atomicAdd(&a.counters->samples, (unsigned long long)wsamples);
+            atomicAdd(&a.counters->wave_iters, (unsigned long long)witers);
+        }
+    }
+}
+
+// frame[i] = (uint8)(sum * (1.0f / samples * 255.0f)), 4 pixels (12 bytes =
+// 3 dwords) per work-item so the stores are whole dwords.
+__global__ void __launch_bounds__(256)
+    pt_resolve_kernel(const float4 *__restrict__ accum,
+                      uint8_t *__restrict__ frame, uint64_t npixels) {
+    const uint64_t quad = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t first = quad * 4u;
+    if (first >= npixels)
+        return;
+    uint8_t bytes[12];
+    const uint32_t count = (npixels - first) < 4u ? (uint32_t)(npixels - first) : 4u;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+        if (k < count) {
+            const float4 s = accum[first + k];
+            const float scale = 1.0f / s.w * 255.0f;
+            bytes[3 * k + 0] = (uint8_t)(s.x * scale);
+            bytes[3 * k + 1] = (uint8_t)(s.y * scale);
+            bytes[3 * k + 2] = (uint8_t)(s.z * scale);
+        } else {
+            bytes[3 * k + 0] = bytes[3 * k + 1] = bytes[3 * k + 2] = 0;
+        }
+    }
+    uint8_t *dst = frame + 3u * first;
+    if (count == 4u && ((reinterpret_cast<uintptr_t>(dst) & 3u) == 0u)) {
+        uint32_t w0 = bytes[0] | (bytes[1] << 8) | (bytes[2] << 16) | ((uint32_t)bytes[3] << 24);
+        uint32_t w1 = bytes[4] | (bytes[5] << 8) | (bytes[6] << 16) | ((uint32_t)bytes[7] << 24);
+        uint32_t w2 = bytes[8] | (bytes[9] << 8) | (bytes[10] << 16) | ((uint32_t)bytes[11] << 24);
+        uint32_t *d32 = reinterpret_cast<uint32_t *>(dst);
+        d32[0] = w0;
+        d32[1] = w1;
+        d32[2] = w2;
+    } else {
+        for (uint32_t k = 0; k < 3u * count; ++k)
+            dst[k] = bytes[k];
+    }
+}
+
+// One work-item per query ray: the batched trace_ray of include/ray.h:14-15.
+__global__ void __launch_bounds__(256)
+    pt_trace_kernel(const SceneDesc scene, const float *__restrict__ origins,
+                    const float *__restrict__ directions, uint64_t n,
+                    DeviceRayHit *__restrict__ hits) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // every lane walks the object loop (it is wave-uniform); lanes past the
+    // end trace a dummy ray and store nothing
+    const bool valid = i < n;
+    const uint64_t at = valid ? i : 0;
+    SceneRecords rec;
+    rec.geom = scene.geom;
+    rec.tri = scene.tri;
+    rec.mat = scene.mat;
+    rec.meta = scene.meta;
+    rec.n_obj = scene.n_obj;
+    const V3 o = V3{origins[3 * at], origins[3 * at + 1], origins[3 * at + 2]};
+    const V3 d = V3{directions[3 * at], directions[3 * at + 1],
+                    directions[3 * at + 2]};
+    const Hit h = closest_hit(rec, o, d);
+    DeviceRayHit out;
+    out.distance = h.distance;
+    out.point[0] = out.point[1] = out.point[2] = 0.0f;
+    out.normal[0] = out.normal[1] = out.normal[2] = 0.0f;
+    out.pad = 0;
+    out.material = 0;
+    if (h.object >= 0) {
+        const Surface sf = surface_at(rec, o, d, h);
+        out.point[0] = sf.point.x;
+        out.point[1] = sf.point.y;
+        out.point[2] = sf.point.z;
+        out.normal[0] = sf.normal.x;
+        out.normal[1] = sf.normal.y;
+        out.normal[2] = sf.normal.z;
+        out.material = sf.material;
+    }
+    if (valid)
+        hits[i] = out;
+}
+
+// ---------------------------------------------------------------------------
+// Launchers (called from the C-ABI layer).
+// ---------------------------------------------------------------------------
+template <bool kLds, bool kTree>
+static hipError_t launch_variant(const LaunchArgs &a, uint32_t grid,
+                                 uint32_t block, size_t lds_bytes,
+                                 hipStream_t stream) {
+    auto kernel = pt_megakernel<kLds, kTree>;
+    if (lds_bytes > 64u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess)
+            return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+size_t megakernel_lds_bytes(const LaunchArgs &a, uint32_t block, bool tree) {
+    size_t bytes = 0;
+    if (a.scene_in_lds)
+        bytes += scene_lds_bytes(a.scene.n_obj, a.scene.n_tri, a.scene.n_mat);
+    if (!tree)
+        bytes += (size_t)2 * block * ((size_t)a.max_bounces + 1u);
+    return (bytes + 15u) & ~(size_t)15u;
+}
+
+hipError_t launch_megakernel(const LaunchArgs &a, uint32_t block, bool tree,
+                             hipStream_t stream) {
+    const uint64_t npix = (uint64_t)a.num_rows * a.framew;
+    if (npix == 0 || a.spp == 0)
+        return hipSuccess;
+    const uint32_t grid = (uint32_t)((npix + block - 1) / block);
+    const size_t lds = megakernel_lds_bytes(a, block, tree);
+    if (a.scene_in_lds)
+        return tree ? launch_variant<true, true>(a, grid, block, lds, stream)
+                    : launch_variant<true, false>(a, grid, block, lds, stream);
+    return tree ? launch_variant<false, true>(a, grid, block, lds, stream)
+                : launch_variant<false, false>(a, grid, block, lds, stream);
+}
+
+hipError_t launch_resolve(const float *accum, uint8_t *frame, uint64_t npixels,
+                          hipStream_t stream) {
+    if (npixels == 0)
+        return hipSuccess;
+    const uint64_t quads = (npixels + 3u) / 4u;
+    const uint32_t grid = (uint32_t)((quads + 255u) / 256u);
+    hipLaunchKernelGGL(pt_resolve_kernel, dim3(grid), dim3(256), 0, stream,
+                       reinterpret_cast<const float4 *>(accum), frame, npixels);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace(const SceneDesc &scene, const float *origins,
+                        const float *directions, uint64_t n,
+                        DeviceRayHit *hits, hipStream_t stream) {
+    if (n == 0)
+        return hipSuccess;
+    const uint32_t grid = (uint32_t)((n + 255u) / 256u);
+    hipLaunchKernelGGL(pt_trace_kernel, dim3(grid), dim3(256), 0, stream, scene,
+                       origins, directions, n, hits);
+    return hipGetLastError();
+}
+
+} // namespace pt

@@ -1,0 +1,32 @@
+// pt_launch.h -- internal C++ interface between the C-ABI layer
+// (ptgpu_abi.hip) and the kernels (pt_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "pt_layout.h"
+
+namespace pt {
+
+// Byte-for-byte the legacy `ray_hit` (include/ray.h:7-12): 40 bytes.
+struct DeviceRayHit {
+    float distance;
+    float point[3];
+    float normal[3];
+    uint32_t pad;
+    uint64_t material;
+};
+static_assert(sizeof(DeviceRayHit) == 40, "must match ray_hit");
+
+// Dynamic LDS one workgroup of `block` work-items needs for this launch.
+size_t megakernel_lds_bytes(const LaunchArgs &a, uint32_t block, bool tree);
+
+hipError_t launch_megakernel(const LaunchArgs &a, uint32_t block, bool tree,
+                             hipStream_t stream);
+hipError_t launch_resolve(const float *accum, uint8_t *frame, uint64_t npixels,
+                          hipStream_t stream);
+hipError_t launch_trace(const SceneDesc &scene, const float *origins,
+                        const float *directions, uint64_t n,
+                        DeviceRayHit *hits, hipStream_t stream);
+
+} // namespace pt

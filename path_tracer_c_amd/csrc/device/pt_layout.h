@@ -1,0 +1,84 @@
+// pt_layout.h -- how a scene lies in HBM / LDS for the megakernel, and the
+// argument block of one launch.  Shared by the uploader (host) and the
+// kernels (device).
+//
+// The reference scans an array of 56-byte tagged unions by value
+// (include/shapes.h:29-36, src/ray.c:12-13) and fetches a 44-byte material per
+// hit (src/renderer.c:34).  Device layout instead, all 16-byte records:
+//
+//   geom[i]  float4   sphere  : centre.xyz, radius*radius
+//                     triangle: v0.xyz, bits(triangle ordinal k)
+//   meta[i]  uint32   bit 31 = triangle, bits 0..30 = material index
+//   tri[3k..3k+2]     float4  edge1 = v1-v0 | edge2 = v2-v0 | unit normal
+//                     crossn(v0-v1, v0-v2) (src/ray.c:50-52), w unused
+//   mat[2m], mat[2m+1] float4 albedo.rgb, roughness*0.5 |
+//                     emission_color*emission_strength, transparency
+//
+// Object ORDER is the scene's: the closest-hit rule of src/ray.c:25,45 is
+// order dependent in its degenerate cases (a hit at distance <= 0 is replaced
+// by any later hit), so no reordering by type.  Everything precomputed here
+// is the value the per-ray code would compute with the same binary32
+// operations (r*r, v1-v0, the unit normal, Le), so hoisting it changes no bit.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define PT_LAYOUT_HD __host__ __device__ inline
+#else
+#define PT_LAYOUT_HD inline
+#endif
+
+namespace pt {
+
+constexpr uint32_t kMetaTriangle = 0x80000000u;
+constexpr uint32_t kMetaMaterialMask = 0x7FFFFFFFu;
+
+struct F4 { // plain 16-byte record usable on host and device
+    float x, y, z, w;
+};
+
+// One device-resident scene: a single allocation, records at these offsets.
+struct SceneDesc {
+    const F4 *geom;       // n_obj
+    const F4 *tri;        // 3 * n_tri
+    const F4 *mat;        // 2 * n_mat
+    const uint32_t *meta; // n_obj
+    uint32_t n_obj;
+    uint32_t n_tri;
+    uint32_t n_mat;
+    uint32_t branching; // some material has 0 < transparency < 1
+    float sky[3];
+    uint32_t pad;
+};
+
+// LDS bytes the scene copy needs (16-byte records first, then meta).
+PT_LAYOUT_HD size_t scene_lds_bytes(uint32_t n_obj, uint32_t n_tri, uint32_t n_mat) {
+    size_t b = (size_t)16 * ((size_t)n_obj + 3u * (size_t)n_tri + 2u * (size_t)n_mat);
+    b += (size_t)4 * n_obj;
+    return (b + 15u) & ~(size_t)15u;
+}
+
+struct Counters { // device-side statistics, one instance per device
+    unsigned long long rays;
+    unsigned long long samples;
+    unsigned long long wave_iters;
+    unsigned long long launches;
+};
+
+struct LaunchArgs {
+    SceneDesc scene;
+    uint8_t *frame;      // RGB8 destination, or nullptr in accumulate mode
+    float *accum;        // float4 per destination pixel, or nullptr
+    Counters *counters;  // may be nullptr
+    uint32_t framew, frameh;
+    uint32_t num_rows;   // rows in this call's row set
+    uint32_t row_begin, tile_rows, tile_stride;
+    uint32_t compact;    // 1: destination row = local row, 0: = global row
+    uint32_t spp, sample_offset, max_bounces, seed;
+    float tan_half_fov;
+    uint32_t scene_in_lds;
+};
+
+} // namespace pt

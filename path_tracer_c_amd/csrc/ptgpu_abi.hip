@@ -1,0 +1,776 @@
+// ptgpu_abi.hip -- the C-ABI of the MI355X render path (include/ptgpu.h) and
+// the legacy entry points it stands behind (include/path_tracer_api.h:
+// render_task, trace_ray, threadpool_*).
+//
+// What replaces what (reference file:line):
+//   threadpool_add_task / _wait_for_tasks   src/threadpool.c:84-101
+//     -> rows are queued on the host; wait_for_tasks renders all queued rows
+//        of a frame with one megakernel launch per contiguous row run and
+//        copies them into the caller's frame.  It returns when every queued
+//        task has completed (the intended contract; the reference returns
+//        early and can lose the wake-up).
+//   render_task                              src/renderer.c:92-116
+//     -> a one-row launch of the same kernel.
+//   trace_ray                                src/ray.c:4-73
+//     -> a one-ray launch of the batched query kernel.
+// There is no CPU implementation of any of these in this library: if HIP is
+// unusable the explicit API returns PTGPU_ERR_NO_DEVICE and the void legacy
+// functions print the reason and abort().
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "device/pt_launch.h"
+#include "device/pt_vec.h"
+#include "ptgpu.h"
+
+namespace {
+
+thread_local std::string g_last_error = "";
+
+int fail(int code, const std::string &what) {
+    g_last_error = what;
+    return code;
+}
+
+int fail_hip(hipError_t e, const char *where) {
+    std::string msg = std::string(where) + ": " + hipGetErrorString(e);
+    const bool no_device = (e == hipErrorNoDevice || e == hipErrorInvalidDevice ||
+                            e == hipErrorInsufficientDriver ||
+                            e == hipErrorNotInitialized);
+    return fail(no_device ? PTGPU_ERR_NO_DEVICE : PTGPU_ERR_HIP, msg);
+}
+
+#define PT_TRY_HIP(expr)                                                       \
+    do {                                                                       \
+        hipError_t pt_e_ = (expr);                                             \
+        if (pt_e_ != hipSuccess)                                               \
+            return fail_hip(pt_e_, #expr);                                     \
+    } while (0)
+
+constexpr int kMaxDevices = 64;
+constexpr size_t kLdsBudget = 160u * 1024u; // one workgroup may own it all
+
+// Per-device statistics block, allocated on first use.
+std::mutex g_ctx_mutex;
+pt::Counters *g_counters[kMaxDevices] = {nullptr};
+
+int current_device(int *dev) {
+    PT_TRY_HIP(hipGetDevice(dev));
+    if (*dev < 0 || *dev >= kMaxDevices)
+        return fail(PTGPU_ERR_LIMIT, "device ordinal out of range");
+    return PTGPU_OK;
+}
+
+int counters_for_current_device(pt::Counters **out) {
+    int dev = 0;
+    int rc = current_device(&dev);
+    if (rc != PTGPU_OK)
+        return rc;
+    std::lock_guard<std::mutex> guard(g_ctx_mutex);
+    if (g_counters[dev] == nullptr) {
+        pt::Counters *c = nullptr;
+        PT_TRY_HIP(hipMalloc(&c, sizeof(pt::Counters)));
+        PT_TRY_HIP(hipMemset(c, 0, sizeof(pt::Counters)));
+        g_counters[dev] = c;
+    }
+    *out = g_counters[dev];
+    return PTGPU_OK;
+}
+
+pt::V3 to_v3(const vec3s &v) { return pt::V3{v.x, v.y, v.z}; }
+
+} // namespace
+
+// The opaque handle of include/ptgpu.h.
+struct ptgpu_scene {
+    int device;
+    void *blob;          // one allocation: geom | tri | mat | meta
+    size_t blob_bytes;
+    pt::SceneDesc desc;  // device pointers into blob
+};
+
+extern "C" {
+
+// ---------------------------------------------------------------------------
+// parameters
+// ---------------------------------------------------------------------------
+int ptgpu_params_default(ptgpu_params *p) {
+    if (p == nullptr)
+        return fail(PTGPU_ERR_INVALID, "params is NULL");
+    std::memset(p, 0, sizeof *p);
+    p->spp = 16;        // NUM_SAMPLES, src/renderer.c:9
+    p->max_bounces = 4; // MAX_BOUNCES, src/renderer.c:8
+    // FOV, src/renderer.c:7: M_PI / 180.f * 90.0f (double), used as
+    // tanf(FOV / 2.0f); halving commutes with the narrowing to float.
+    p->fov_rad = (float)(M_PI / 180.f * 90.0f);
+    p->seed = 1;
+    p->tile_stride = 1;
+    return PTGPU_OK;
+}
+
+static bool env_u32(const char *name, uint32_t *out) {
+    const char *v = std::getenv(name);
+    if (v == nullptr || *v == '\0')
+        return false;
+    char *end = nullptr;
+    unsigned long long x = std::strtoull(v, &end, 0);
+    if (end == v)
+        return false;
+    *out = (uint32_t)x;
+    return true;
+}
+
+int ptgpu_params_from_env(ptgpu_params *p) {
+    int rc = ptgpu_params_default(p);
+    if (rc != PTGPU_OK)
+        return rc;
+    env_u32("PTGPU_SPP", &p->spp);
+    env_u32("PTGPU_BOUNCES", &p->max_bounces);
+    env_u32("PTGPU_SEED", &p->seed);
+    env_u32("PTGPU_BLOCK", &p->block_threads);
+    env_u32("PTGPU_FLAGS", &p->flags);
+    if (const char *deg = std::getenv("PTGPU_FOV_DEG")) {
+        char *end = nullptr;
+        double d = std::strtod(deg, &end);
+        if (end != deg && d > 0.0 && d < 180.0)
+            p->fov_rad = (float)(M_PI / 180.0 * d);
+    }
+    return PTGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// devices
+// ---------------------------------------------------------------------------
+int ptgpu_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess)
+        return fail_hip(e, "hipGetDeviceCount");
+    return n;
+}
+
+int ptgpu_set_device(int device) {
+    PT_TRY_HIP(hipSetDevice(device));
+    return PTGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// scene residency
+// ---------------------------------------------------------------------------
+int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
+    if (host == nullptr || out == nullptr)
+        return fail(PTGPU_ERR_INVALID, "scene or out pointer is NULL");
+    *out = nullptr;
+    if (host->num_objects > 0x7FFFFFF0u)
+        return fail(PTGPU_ERR_LIMIT, "too many objects");
+    if (host->num_materials > 65536u)
+        return fail(PTGPU_ERR_LIMIT,
+                    "more than 65536 materials (16-bit bounce stack)");
+    if ((host->num_objects && host->objects == nullptr) ||
+        (host->num_materials && host->materials == nullptr))
+        return fail(PTGPU_ERR_INVALID, "scene arrays are NULL");
+
+    const uint32_t n_obj = (uint32_t)host->num_objects;
+    const uint32_t n_mat = (uint32_t)host->num_materials;
+    uint32_t n_tri = 0;
+    for (uint32_t i = 0; i < n_obj; ++i) {
+        const shape &o = host->objects[i];
+        if (o.tag != 0 && o.tag != 1)
+            return fail(PTGPU_ERR_INVALID, "object with unknown tag");
+        if (o.material >= n_mat)
+            return fail(PTGPU_ERR_INVALID, "object refers to a missing material");
+        n_tri += (o.tag == 1);
+    }
+
+    const size_t bytes = pt::scene_lds_bytes(n_obj, n_tri, n_mat);
+    std::vector<unsigned char> blob(bytes ? bytes : 16, 0);
+    pt::F4 *geom = reinterpret_cast<pt::F4 *>(blob.data());
+    pt::F4 *tri = geom + n_obj;
+    pt::F4 *mat = tri + 3u * (size_t)n_tri;
+    uint32_t *meta = reinterpret_cast<uint32_t *>(mat + 2u * (size_t)n_mat);
+
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < n_obj; ++i) {
+        const shape &o = host->objects[i];
+        if (o.tag == 0) { // SPHERE
+            const float r = o.sphere.radius;
+            geom[i] = pt::F4{o.sphere.center.x, o.sphere.center.y,
+                             o.sphere.center.z, r * r};
+            meta[i] = (uint32_t)o.material;
+        } else { // TRIANGLE
+            const pt::V3 v0 = to_v3(o.triangle.v0), v1 = to_v3(o.triangle.v1),
+                         v2 = to_v3(o.triangle.v2);
+            const pt::V3 e1 = v1 - v0, e2 = v2 - v0;
+            // glms_vec3_crossn(v0 - v1, v0 - v2), src/ray.c:50-52
+            const pt::V3 n = pt::normalize(pt::cross(v0 - v1, v0 - v2));
+            float kbits;
+            std::memcpy(&kbits, &k, sizeof kbits);
+            geom[i] = pt::F4{v0.x, v0.y, v0.z, kbits};
+            tri[3 * k + 0] = pt::F4{e1.x, e1.y, e1.z, 0.0f};
+            tri[3 * k + 1] = pt::F4{e2.x, e2.y, e2.z, 0.0f};
+            tri[3 * k + 2] = pt::F4{n.x, n.y, n.z, 0.0f};
+            meta[i] = (uint32_t)o.material | pt::kMetaTriangle;
+            ++k;
+        }
+    }
+    uint32_t branching = 0;
+    for (uint32_t m = 0; m < n_mat; ++m) {
+        const shape_material &s = host->materials[m];
+        // src/renderer.c:37,40: Le = emission_color * emission_strength;
+        // deviation scale = roughness * 0.5
+        const pt::V3 le = to_v3(s.emission_color) * s.emission_strength;
+        mat[2 * m + 0] = pt::F4{s.albedo.x, s.albedo.y, s.albedo.z,
+                                (float)((double)s.roughness * 0.5)};
+        mat[2 * m + 1] = pt::F4{le.x, le.y, le.z, s.transparency};
+        if (s.transparency > 0.0f && s.transparency < 1.0f)
+            branching = 1;
+    }
+
+    ptgpu_scene *h = new (std::nothrow) ptgpu_scene();
+    if (h == nullptr)
+        return fail(PTGPU_ERR_NOMEM, "out of host memory");
+    hipError_t e = hipGetDevice(&h->device);
+    if (e == hipSuccess)
+        e = hipMalloc(&h->blob, blob.size());
+    if (e == hipSuccess)
+        e = hipMemcpy(h->blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (h->blob)
+            (void)hipFree(h->blob);
+        delete h;
+        return fail_hip(e, "scene upload");
+    }
+    h->blob_bytes = blob.size();
+    const pt::F4 *dbase = reinterpret_cast<const pt::F4 *>(h->blob);
+    h->desc.geom = dbase;
+    h->desc.tri = dbase + n_obj;
+    h->desc.mat = dbase + n_obj + 3u * (size_t)n_tri;
+    h->desc.meta = reinterpret_cast<const uint32_t *>(dbase + n_obj +
+                                                      3u * (size_t)n_tri +
+                                                      2u * (size_t)n_mat);
+    h->desc.n_obj = n_obj;
+    h->desc.n_tri = n_tri;
+    h->desc.n_mat = n_mat;
+    h->desc.branching = branching;
+    h->desc.sky[0] = host->sky_color.x;
+    h->desc.sky[1] = host->sky_color.y;
+    h->desc.sky[2] = host->sky_color.z;
+    h->desc.pad = 0;
+    *out = h;
+    return PTGPU_OK;
+}
+
+void ptgpu_scene_free(ptgpu_scene *s) {
+    if (s == nullptr)
+        return;
+    if (s->blob)
+        (void)hipFree(s->blob);
+    delete s;
+}
+
+int ptgpu_scene_is_branching(const ptgpu_scene *s) {
+    if (s == nullptr)
+        return fail(PTGPU_ERR_INVALID, "scene is NULL");
+    return (int)s->desc.branching;
+}
+
+// ---------------------------------------------------------------------------
+// rendering
+// ---------------------------------------------------------------------------
+namespace {
+
+// Validates a call and fills the launch block.  `dest_rows` is the number of
+// rows the destination buffer must hold.
+int prepare_launch(const ptgpu_scene *s, size_t framew, size_t frameh,
+                   const ptgpu_params *p, pt::LaunchArgs *a, uint32_t *block,
+                   bool *tree) {
+    if (s == nullptr || p == nullptr)
+        return fail(PTGPU_ERR_INVALID, "scene or params is NULL");
+    if (framew == 0 || frameh == 0 || framew > 0xFFFFu * 16u ||
+        frameh > 0xFFFFu * 16u || framew * frameh > 0xFFFFFFFFull)
+        return fail(PTGPU_ERR_INVALID, "frame size out of range");
+    if (p->spp == 0)
+        return fail(PTGPU_ERR_INVALID, "spp must be >= 1");
+    if (p->row_begin >= frameh)
+        return fail(PTGPU_ERR_INVALID, "row_begin is below the frame");
+
+    uint32_t num_rows = p->num_rows;
+    const uint32_t stride = p->tile_stride ? p->tile_stride : 1u;
+    if (num_rows == 0) {
+        if (p->tile_rows != 0 && stride != 1)
+            return fail(PTGPU_ERR_INVALID,
+                        "num_rows must be given for a strided tile set");
+        num_rows = (uint32_t)frameh - p->row_begin;
+    }
+    // last global row of the set must exist
+    uint64_t last = (uint64_t)p->row_begin + (num_rows - 1u);
+    if (p->tile_rows != 0) {
+        const uint64_t tile = (num_rows - 1u) / p->tile_rows;
+        last = (uint64_t)p->row_begin + tile * p->tile_rows * stride +
+               ((num_rows - 1u) % p->tile_rows);
+    }
+    if (last >= frameh)
+        return fail(PTGPU_ERR_INVALID, "row set reaches below the frame");
+
+    *tree = s->desc.branching || (p->flags & PTGPU_FLAG_FORCE_TREE);
+    if (*tree && p->max_bounces > PTGPU_MAX_BOUNCES_TREE)
+        return fail(PTGPU_ERR_LIMIT,
+                    "max_bounces exceeds the branching kernel's frame stack");
+    if (!*tree && p->max_bounces > PTGPU_MAX_BOUNCES_PATH)
+        return fail(PTGPU_ERR_LIMIT, "max_bounces exceeds the kernel's limit");
+
+    uint32_t b = p->block_threads ? p->block_threads : 256u;
+    if (b % 64u != 0 || b > 1024u)
+        return fail(PTGPU_ERR_INVALID,
+                    "block_threads must be a multiple of 64, at most 1024");
+    *block = b;
+
+    std::memset(a, 0, sizeof *a);
+    a->scene = s->desc;
+    a->framew = (uint32_t)framew;
+    a->frameh = (uint32_t)frameh;
+    a->num_rows = num_rows;
+    a->row_begin = p->row_begin;
+    a->tile_rows = p->tile_rows;
+    a->tile_stride = stride;
+    a->compact = (p->flags & PTGPU_FLAG_COMPACT_ROWS) ? 1u : 0u;
+    a->spp = p->spp;
+    a->sample_offset = p->sample_offset;
+    a->max_bounces = p->max_bounces;
+    a->seed = p->seed;
+    a->tan_half_fov = tanf(p->fov_rad / 2.0f); // src/renderer.c:77
+    a->scene_in_lds = (p->flags & PTGPU_FLAG_SCENE_GLOBAL) ? 0u : 1u;
+    if (a->scene_in_lds &&
+        pt::megakernel_lds_bytes(*a, b, *tree) > kLdsBudget)
+        a->scene_in_lds = 0; // too large for one CU's LDS: scan from L2/HBM
+    if (pt::megakernel_lds_bytes(*a, b, *tree) > kLdsBudget)
+        return fail(PTGPU_ERR_LIMIT, "bounce stack does not fit LDS; "
+                                     "lower max_bounces or block_threads");
+
+    a->counters = nullptr;
+    if (!(p->flags & PTGPU_FLAG_NO_RAY_COUNT)) {
+        int rc = counters_for_current_device(&a->counters);
+        if (rc != PTGPU_OK)
+            return rc;
+    }
+    return PTGPU_OK;
+}
+
+// launches are counted on the host (per device)
+std::atomic<unsigned long long> g_launches[kMaxDevices];
+
+void count_launch() {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices)
+        g_launches[dev].fetch_add(1, std::memory_order_relaxed);
+}
+
+} // namespace
+
+int ptgpu_render_device(const ptgpu_scene *s, uint8_t *d_frame, size_t framew,
+                        size_t frameh, const ptgpu_params *p,
+                        void *hip_stream) {
+    if (d_frame == nullptr)
+        return fail(PTGPU_ERR_INVALID, "d_frame is NULL");
+    pt::LaunchArgs a;
+    uint32_t block = 0;
+    bool tree = false;
+    int rc = prepare_launch(s, framew, frameh, p, &a, &block, &tree);
+    if (rc != PTGPU_OK)
+        return rc;
+    a.frame = d_frame;
+    a.accum = nullptr;
+    hipError_t e =
+        pt::launch_megakernel(a, block, tree, (hipStream_t)hip_stream);
+    if (e != hipSuccess)
+        return fail_hip(e, "megakernel launch");
+    count_launch();
+    return PTGPU_OK;
+}
+
+int ptgpu_accumulate_device(const ptgpu_scene *s, float *d_accum,
+                            size_t framew, size_t frameh,
+                            const ptgpu_params *p, void *hip_stream) {
+    if (d_accum == nullptr)
+        return fail(PTGPU_ERR_INVALID, "d_accum is NULL");
+    if ((reinterpret_cast<uintptr_t>(d_accum) & 15u) != 0)
+        return fail(PTGPU_ERR_INVALID, "d_accum must be 16-byte aligned");
+    pt::LaunchArgs a;
+    uint32_t block = 0;
+    bool tree = false;
+    int rc = prepare_launch(s, framew, frameh, p, &a, &block, &tree);
+    if (rc != PTGPU_OK)
+        return rc;
+    a.frame = nullptr;
+    a.accum = d_accum;
+    hipError_t e =
+        pt::launch_megakernel(a, block, tree, (hipStream_t)hip_stream);
+    if (e != hipSuccess)
+        return fail_hip(e, "megakernel launch (accumulate)");
+    count_launch();
+    return PTGPU_OK;
+}
+
+int ptgpu_resolve_device(const float *d_accum, uint8_t *d_frame,
+                         size_t npixels, void *hip_stream) {
+    if (d_accum == nullptr || d_frame == nullptr)
+        return fail(PTGPU_ERR_INVALID, "NULL buffer");
+    hipError_t e = pt::launch_resolve(d_accum, d_frame, (uint64_t)npixels,
+                                      (hipStream_t)hip_stream);
+    if (e != hipSuccess)
+        return fail_hip(e, "resolve launch");
+    return PTGPU_OK;
+}
+
+namespace {
+
+// Global row of local row i of a call (same map as the kernel's).
+uint32_t global_row(const pt::LaunchArgs &a, uint32_t i) {
+    if (a.tile_rows == 0)
+        return a.row_begin + i;
+    const uint32_t tile = i / a.tile_rows;
+    return a.row_begin + tile * a.tile_rows * a.tile_stride + (i % a.tile_rows);
+}
+
+int render_frame_with(const ptgpu_scene *s, uint8_t *frame, size_t framew,
+                      size_t frameh, const ptgpu_params *p) {
+    ptgpu_params q = *p;
+    q.flags |= PTGPU_FLAG_COMPACT_ROWS;
+    pt::LaunchArgs a;
+    uint32_t block = 0;
+    bool tree = false;
+    int rc = prepare_launch(s, framew, frameh, &q, &a, &block, &tree);
+    if (rc != PTGPU_OK)
+        return rc;
+    const size_t row_bytes = 3u * framew;
+    const size_t bytes = row_bytes * a.num_rows;
+    uint8_t *d_rows = nullptr;
+    PT_TRY_HIP(hipMalloc(&d_rows, bytes));
+    a.frame = d_rows;
+    hipError_t e = pt::launch_megakernel(a, block, tree, nullptr);
+    count_launch();
+    if (e == hipSuccess)
+        e = hipDeviceSynchronize();
+    // copy back run by run (a run = consecutive local rows that are also
+    // consecutive global rows)
+    uint32_t i = 0;
+    while (e == hipSuccess && i < a.num_rows) {
+        uint32_t j = i + 1;
+        while (j < a.num_rows && global_row(a, j) == global_row(a, j - 1) + 1)
+            ++j;
+        e = hipMemcpy(frame + row_bytes * global_row(a, i),
+                      d_rows + row_bytes * i, row_bytes * (j - i),
+                      hipMemcpyDeviceToHost);
+        i = j;
+    }
+    (void)hipFree(d_rows);
+    if (e != hipSuccess)
+        return fail_hip(e, "render_frame");
+    return PTGPU_OK;
+}
+
+} // namespace
+
+int ptgpu_render_frame(const scene *host_scene, uint8_t *frame, size_t framew,
+                       size_t frameh, const ptgpu_params *p) {
+    if (frame == nullptr)
+        return fail(PTGPU_ERR_INVALID, "frame is NULL");
+    ptgpu_params defaults;
+    if (p == nullptr) {
+        ptgpu_params_default(&defaults);
+        p = &defaults;
+    }
+    ptgpu_scene *s = nullptr;
+    int rc = ptgpu_scene_upload(host_scene, &s);
+    if (rc != PTGPU_OK)
+        return rc;
+    rc = render_frame_with(s, frame, framew, frameh, p);
+    ptgpu_scene_free(s);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
+// batched closest-hit queries
+// ---------------------------------------------------------------------------
+int ptgpu_trace_rays(const scene *host_scene, const float *origins,
+                     const float *directions, size_t n, ray_hit *hits) {
+    if (n == 0)
+        return PTGPU_OK;
+    if (origins == nullptr || directions == nullptr || hits == nullptr)
+        return fail(PTGPU_ERR_INVALID, "NULL ray buffer");
+    static_assert(sizeof(ray_hit) == sizeof(pt::DeviceRayHit), "ray_hit size");
+    ptgpu_scene *s = nullptr;
+    int rc = ptgpu_scene_upload(host_scene, &s);
+    if (rc != PTGPU_OK)
+        return rc;
+    float *d_o = nullptr, *d_d = nullptr;
+    pt::DeviceRayHit *d_h = nullptr;
+    const size_t vec_bytes = 3u * sizeof(float) * n;
+    hipError_t e = hipMalloc(&d_o, vec_bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_d, vec_bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_h, sizeof(pt::DeviceRayHit) * n);
+    if (e == hipSuccess) e = hipMemcpy(d_o, origins, vec_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_d, directions, vec_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = pt::launch_trace(s->desc, d_o, d_d, n, d_h, nullptr);
+    if (e == hipSuccess)
+        e = hipMemcpy(hits, d_h, sizeof(pt::DeviceRayHit) * n, hipMemcpyDeviceToHost);
+    if (d_o) (void)hipFree(d_o);
+    if (d_d) (void)hipFree(d_d);
+    if (d_h) (void)hipFree(d_h);
+    ptgpu_scene_free(s);
+    if (e != hipSuccess)
+        return fail_hip(e, "trace_rays");
+    return PTGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// bookkeeping
+// ---------------------------------------------------------------------------
+int ptgpu_stats_reset(void) {
+    pt::Counters *c = nullptr;
+    int rc = counters_for_current_device(&c);
+    if (rc != PTGPU_OK)
+        return rc;
+    PT_TRY_HIP(hipDeviceSynchronize());
+    PT_TRY_HIP(hipMemset(c, 0, sizeof *c));
+    int dev = 0;
+    if (current_device(&dev) == PTGPU_OK)
+        g_launches[dev].store(0);
+    return PTGPU_OK;
+}
+
+int ptgpu_stats_read(ptgpu_stats *out) {
+    if (out == nullptr)
+        return fail(PTGPU_ERR_INVALID, "out is NULL");
+    pt::Counters *c = nullptr;
+    int rc = counters_for_current_device(&c);
+    if (rc != PTGPU_OK)
+        return rc;
+    pt::Counters host;
+    PT_TRY_HIP(hipDeviceSynchronize());
+    PT_TRY_HIP(hipMemcpy(&host, c, sizeof host, hipMemcpyDeviceToHost));
+    out->rays = host.rays;
+    out->samples = host.samples;
+    out->wave_iters = host.wave_iters;
+    int dev = 0;
+    out->launches = (current_device(&dev) == PTGPU_OK) ? g_launches[dev].load() : 0;
+    return PTGPU_OK;
+}
+
+const char *ptgpu_last_error(void) { return g_last_error.c_str(); }
+
+const char *ptgpu_version(void) { return "path_tracer_c_amd 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------------------
+// legacy entry points
+// ---------------------------------------------------------------------------
+namespace {
+
+[[noreturn]] void die(const char *who) {
+    std::fprintf(stderr,
+                 "path_tracer (MI355X path): %s failed: %s\n"
+                 "  this library has no CPU renderer to fall back to.\n",
+                 who, g_last_error.c_str());
+    std::abort();
+}
+
+// One cached device scene for the legacy calls, revalidated by content hash
+// so a caller may edit its scene between frames (the reference's RT loop
+// does, src/main.c:260-263).
+struct CachedScene {
+    const scene *key = nullptr;
+    uint64_t hash = 0;
+    int device = -1;
+    ptgpu_scene *dev = nullptr;
+};
+std::mutex g_cache_mutex;
+CachedScene g_cache;
+
+uint64_t fnv1a(const void *data, size_t n, uint64_t h) {
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    for (size_t i = 0; i < n; ++i) {
+        h ^= p[i];
+        h *= 0x100000001B3ull;
+    }
+    return h;
+}
+
+uint64_t scene_hash(const scene *w) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    h = fnv1a(&w->num_objects, sizeof w->num_objects, h);
+    h = fnv1a(&w->num_materials, sizeof w->num_materials, h);
+    h = fnv1a(&w->sky_color, sizeof w->sky_color, h);
+    if (w->num_objects)
+        h = fnv1a(w->objects, w->num_objects * sizeof(shape), h);
+    if (w->num_materials)
+        h = fnv1a(w->materials, w->num_materials * sizeof(shape_material), h);
+    return h;
+}
+
+// Returns the cached device copy of `w`, uploading if it changed.
+ptgpu_scene *legacy_scene(const scene *w) {
+    int dev = 0;
+    if (current_device(&dev) != PTGPU_OK)
+        die("hipGetDevice");
+    const uint64_t h = scene_hash(w);
+    if (g_cache.dev != nullptr && g_cache.key == w && g_cache.hash == h &&
+        g_cache.device == dev)
+        return g_cache.dev;
+    ptgpu_scene_free(g_cache.dev);
+    g_cache = CachedScene();
+    ptgpu_scene *s = nullptr;
+    if (ptgpu_scene_upload(w, &s) != PTGPU_OK)
+        die("scene upload");
+    g_cache.key = w;
+    g_cache.hash = h;
+    g_cache.device = dev;
+    g_cache.dev = s;
+    return s;
+}
+
+void legacy_render_rows(const scene *world, uint8_t *frame, size_t framew,
+                        size_t frameh, uint32_t row_begin, uint32_t num_rows) {
+    std::lock_guard<std::mutex> guard(g_cache_mutex);
+    ptgpu_params p;
+    ptgpu_params_from_env(&p);
+    p.row_begin = row_begin;
+    p.num_rows = num_rows;
+    p.tile_rows = 0;
+    p.tile_stride = 1;
+    ptgpu_scene *s = legacy_scene(world);
+    if (render_frame_with(s, frame, framew, frameh, &p) != PTGPU_OK)
+        die("render");
+}
+
+struct PoolTask {
+    void (*fn)(void *);
+    void *arg;
+    bool is_row;
+    render_args row; // snapshot taken when the task was added
+};
+
+} // namespace
+
+void render_task(render_args *arg) {
+    if (arg == nullptr || arg->frame == nullptr || arg->world == nullptr)
+        return;
+    if (arg->screen_y < 0 || (size_t)arg->screen_y >= arg->frameh)
+        return;
+    legacy_render_rows(arg->world, arg->frame, arg->framew, arg->frameh,
+                       (uint32_t)arg->screen_y, 1u);
+}
+
+ray_hit trace_ray(const vec3s origin, const vec3s direction,
+                  const scene *world) {
+    ray_hit hit;
+    std::memset(&hit, 0, sizeof hit);
+    if (ptgpu_trace_rays(world, origin.raw, direction.raw, 1, &hit) != PTGPU_OK)
+        die("trace_ray");
+    return hit;
+}
+
+void threadpool_init(threadpool *pool, size_t num_threads) {
+    // No worker threads: the GPU is the pool.  `threads` stays empty.
+    vector_init_with_capacity(&pool->threads, num_threads ? num_threads : 1);
+    vector_init(&pool->tasks);
+    pthread_mutex_init(&pool->tasks_mutex, nullptr);
+    pthread_cond_init(&pool->tasks_available_cond, nullptr);
+    pthread_cond_init(&pool->tasks_exhausted_cond, nullptr);
+    pool->threads_running = true;
+}
+
+void threadpool_add_task(threadpool *pool, void (*f)(void *), void *arg) {
+    PoolTask *t = new PoolTask();
+    t->fn = f;
+    t->arg = arg;
+    t->is_row = (f == reinterpret_cast<void (*)(void *)>(&render_task)) &&
+                arg != nullptr;
+    if (t->is_row)
+        t->row = *static_cast<render_args *>(arg);
+    pthread_mutex_lock(&pool->tasks_mutex);
+    vector_push(&pool->tasks, t);
+    pthread_cond_signal(&pool->tasks_available_cond);
+    pthread_mutex_unlock(&pool->tasks_mutex);
+}
+
+void threadpool_wait_for_tasks(threadpool *pool) {
+    for (;;) {
+        // take everything queued so far
+        std::vector<PoolTask *> batch;
+        pthread_mutex_lock(&pool->tasks_mutex);
+        while (void *t = vector_pop(&pool->tasks))
+            batch.push_back(static_cast<PoolTask *>(t));
+        pthread_mutex_unlock(&pool->tasks_mutex);
+        if (batch.empty())
+            break;
+
+        // foreign tasks run here, on the waiting thread (popped order = LIFO,
+        // as src/vector.c:24-31 pops)
+        std::vector<PoolTask *> rows;
+        for (PoolTask *t : batch) {
+            if (t->is_row)
+                rows.push_back(t);
+            else if (t->fn)
+                t->fn(t->arg);
+        }
+
+        // group row tasks by (frame, size, scene); render each group's rows
+        // as contiguous runs
+        std::stable_sort(rows.begin(), rows.end(),
+                         [](const PoolTask *x, const PoolTask *y) {
+                             const render_args &a = x->row, &b = y->row;
+                             if (a.frame != b.frame) return a.frame < b.frame;
+                             if (a.world != b.world) return a.world < b.world;
+                             if (a.framew != b.framew) return a.framew < b.framew;
+                             if (a.frameh != b.frameh) return a.frameh < b.frameh;
+                             return a.screen_y < b.screen_y;
+                         });
+        size_t i = 0;
+        while (i < rows.size()) {
+            const render_args &head = rows[i]->row;
+            size_t j = i + 1;
+            while (j < rows.size() && rows[j]->row.frame == head.frame &&
+                   rows[j]->row.world == head.world &&
+                   rows[j]->row.framew == head.framew &&
+                   rows[j]->row.frameh == head.frameh &&
+                   (rows[j]->row.screen_y == rows[j - 1]->row.screen_y ||
+                    rows[j]->row.screen_y == rows[j - 1]->row.screen_y + 1))
+                ++j;
+            const int y0 = head.screen_y, y1 = rows[j - 1]->row.screen_y;
+            if (head.frame && head.world && y0 >= 0 &&
+                (size_t)y1 < head.frameh)
+                legacy_render_rows(head.world, head.frame, head.framew,
+                                   head.frameh, (uint32_t)y0,
+                                   (uint32_t)(y1 - y0 + 1));
+            i = j;
+        }
+        for (PoolTask *t : batch)
+            delete t;
+    }
+    pthread_mutex_lock(&pool->tasks_mutex);
+    pthread_cond_broadcast(&pool->tasks_exhausted_cond);
+    pthread_mutex_unlock(&pool->tasks_mutex);
+}
+
+void threadpool_destroy(threadpool *pool) {
+    pool->threads_running = false;
+    // unexecuted tasks are dropped, as in src/threadpool.c:70-74
+    while (void *t = vector_pop(&pool->tasks))
+        delete static_cast<PoolTask *>(t);
+    vector_free(&pool->threads);
+    vector_free(&pool->tasks);
+    pthread_mutex_destroy(&pool->tasks_mutex);
+    pthread_cond_destroy(&pool->tasks_available_cond);
+    pthread_cond_destroy(&pool->tasks_exhausted_cond);
+}
+
+} // extern "C"

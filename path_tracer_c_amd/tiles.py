@@ -1,0 +1,94 @@
+"""Row-tile sharding of one frame over the GPUs of a node, and the single
+gather that reassembles it.
+
+The reference's unit of parallel work is one image row per task
+(include/renderer.h:6-11, src/threadpool.c:84-95).  Across GPUs the frame is
+cut into tiles of `tile_rows` consecutive rows dealt round-robin: tile t goes
+to rank t mod G, so sky rows and floor rows are spread evenly.  Because the
+sample stream is a function of the GLOBAL pixel index (include/ptgpu_rng.h),
+the assembled frame does not depend on G or on tile_rows: it equals the
+one-GPU frame byte for byte.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI, or
+"gloo" in the CPU tests); the only collective is one `gather` of the ranks'
+compact row buffers to rank 0 at the end of a frame.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+
+@dataclass(frozen=True)
+class RowShard:
+    """The rows rank `rank` of `world` renders, in ptgpu_params terms."""
+    row_begin: int
+    num_rows: int
+    tile_rows: int
+    tile_stride: int
+
+    def global_rows(self):
+        """Global row of each local row, in local order."""
+        rows = []
+        for i in range(self.num_rows):
+            tile, within = divmod(i, self.tile_rows)
+            rows.append(self.row_begin + tile * self.tile_rows * self.tile_stride + within)
+        return rows
+
+
+def shard_rows(height: int, world: int, rank: int, tile_rows: int) -> RowShard:
+    """Interleaved tiles: rank r owns tiles r, r+G, r+2G, ...  The last tile of
+    the frame may be short; it is then the last tile of its owner."""
+    if not (0 <= rank < world) or tile_rows <= 0 or height <= 0:
+        raise ValueError("bad shard request")
+    n_tiles = (height + tile_rows - 1) // tile_rows
+    mine = range(rank, n_tiles, world)
+    rows = 0
+    for t in mine:
+        rows += min(tile_rows, height - t * tile_rows)
+    return RowShard(row_begin=rank * tile_rows, num_rows=rows,
+                    tile_rows=tile_rows, tile_stride=world)
+
+
+def max_shard_rows(height: int, world: int, tile_rows: int) -> int:
+    return max(shard_rows(height, world, r, tile_rows).num_rows for r in range(world))
+
+
+def default_tile_rows(height: int, world: int) -> int:
+    """8-row tiles (one 1080p tile = 15 workgroups of 1024 pixels), shrunk for
+    small frames so every rank gets work."""
+    t = 8
+    while t > 1 and height < t * world:
+        t //= 2
+    return t
+
+
+def gather_frame(local_rows, height: int, width: int, tile_rows: int,
+                 group=None, dst: int = 0):
+    """Gather the ranks' compact row buffers into the full frame on `dst`.
+
+    `local_rows` is a uint8 tensor of shape (padded_rows, width, 3) where
+    padded_rows = max_shard_rows(...) on every rank (equal message sizes for
+    the one gather); only the first shard.num_rows rows are meaningful.
+    Returns the (height, width, 3) frame on `dst`, None elsewhere.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    pad = max_shard_rows(height, world, tile_rows)
+    assert local_rows.shape == (pad, width, 3), (local_rows.shape, pad)
+    parts = None
+    if rank == dst:
+        parts = [torch.empty_like(local_rows) for _ in range(world)]
+    dist.gather(local_rows, gather_list=parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    frame = torch.empty((height, width, 3), dtype=local_rows.dtype,
+                        device=local_rows.device)
+    for r in range(world):
+        shard = shard_rows(height, world, r, tile_rows)
+        idx = torch.tensor(shard.global_rows(), dtype=torch.long,
+                           device=local_rows.device)
+        frame.index_copy_(0, idx, parts[r][: shard.num_rows])
+    return frame
