@@ -1,0 +1,322 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline benchmark of the MI355X render path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is ONE FRAME of BASELINE.json's metric configuration (config 2: the
+8-sphere Cornell-style scene, 1920x1080, 256 samples per pixel, 8 bounces):
+the hot path -- src/renderer.c:92-116 + src/ray.c:4-73 of the reference --
+over every pixel, with the scene already resident in HBM and the frame
+written to HBM.  At N > 1 (launched by torch.distributed.run, one process per
+GPU) the frame is cut into interleaved 8-row tiles, each rank renders its
+tiles, and ONE gather over RCCL/xGMI brings them to rank 0; total work is
+fixed, so scaling is "strong".
+
+Rank 0 prints one JSON line.  `value` is Mray/s = trace_ray-equivalent path
+segments (counted exactly by the kernel) per second of wall time between two
+barrier + device-synchronize brackets, maximum over ranks.  The line also
+carries
+  roofline      the dominant kernel (pt_megakernel) against the FP32 vector
+                ALU roof that bounds it (no MFMA, HBM
+                is not binding), its duration measured here with HIP events
+                on the launch stream, plus the algorithmic HBM rate;
+  cpu_baseline  the CPU oracle (a restatement of the reference; the reference
+                itself cannot be built here) timed on this machine's host
+                cores on a bounded sample of the same frame, N = 1 only;
+  rmse_vs_cpu_ref  per-pixel RMSE of sampled rows of the GPU frame against the
+                CPU oracle (same stream: expected exactly 0) and against the
+                oracle on the reference's glibc random() stream.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+
+METRIC = "Mray/s at 1920x1080, 256 spp, 8 bounces; per-pixel RMSE vs CPU ref"
+# MI355X_MICROARCH.md, chip-level parameters: "Peak FP32 (vector) 157.3 TFLOPS"
+# (packed v_pk_fma_f32 issue; 78.6 TFLOP/s for plain v_fma_f32), HBM3E 8 TB/s.
+PEAK_FP32_VECTOR_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"],
+                    help="BASELINE.json configuration; the metric is quoted on c2")
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
+    ap.add_argument("--pass-spp", type=int, default=256,
+                    help="c3 only: samples per progressive pass")
+    ap.add_argument("--tile-rows", type=int, default=0)
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--flags", type=lambda s: int(s, 0), default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--out", default="", help="write the last frame as BMP (rank 0)")
+    return ap.parse_args()
+
+
+def flop_per_ray(n_spheres, n_triangles):
+    """17 FLOP per ray-sphere test, 45 per ray-triangle
+    test, ~100 per shade step."""
+    return 17 * n_spheres + 45 * n_triangles + 100
+
+
+def cpu_baseline(pt, scene, cfg, gpu_frame_rows):
+    """The oracle on this machine's host cores, on a bounded sample of the same
+    frame: every 8th row with the GPU's stream on all cores (corrected row
+    pool), plus every 128th row on the reference's glibc random() stream."""
+    from oracle import binding as oracle
+
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))   # a one-GPU box's CPU share is 16 cores
+    w, h = cfg["width"], cfg["height"]
+    kw = dict(spp=cfg["spp"], max_bounces=cfg["max_bounces"], seed=cfg["seed"])
+    step = 8
+    t0 = time.perf_counter()
+    frame, rays = oracle.render_mt(scene, w, h, cores, row_begin=0, row_end=h,
+                                   row_step=step, **kw)
+    dt = time.perf_counter() - t0
+    rows = list(range(0, h, step))
+    out = {
+        "value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+        "sample": f"rows 0,{step},{2*step},... ({len(rows)} of {h}) of the same frame, "
+                  f"{rays} rays in {dt:.2f} s; CPU oracle (restated reference, "
+                  "per-pixel xorshift stream) on a corrected row-task pool",
+    }
+    exact = float(np.sqrt(((gpu_frame_rows(rows).astype(np.float64) - frame[rows]) ** 2).mean()))
+
+    # the reference's own generator: process-global random() behind a lock.
+    # One thread is the reference-faithful figure; the same rows on all cores
+    # show the lock (slower than one thread).
+    lrows = [0, h // 2, h - 1]
+    oracle.lib().oracle_srandom(12345)
+    lframe = np.zeros((h, w, 3), dtype=np.uint8)
+    lrays = 0
+    t0 = time.perf_counter()
+    for y in lrows:
+        _, n = oracle.render_rows(scene, w, h, y, y + 1, frame=lframe,
+                                  rng_mode=oracle.RNG_LIBC, **kw)
+        lrays += n
+    ldt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    _, mrays = oracle.render_mt(scene, w, h, cores, row_begin=h // 2, row_end=h // 2 + 2,
+                                row_step=1, rng_mode=oracle.RNG_LIBC, **kw)
+    mdt = time.perf_counter() - t0
+    out["libc_random"] = {
+        "value": lrays / ldt / 1e6, "unit": "Mray/s", "cores": 1,
+        "sample": f"{len(lrows)} rows, {lrays} rays in {ldt:.2f} s, one thread; glibc "
+                  "random() as the reference uses it",
+        "all_cores": {"value": mrays / mdt / 1e6, "cores": cores,
+                      "sample": f"2 rows, {mrays} rays in {mdt:.2f} s (global lock in "
+                                "random(): anti-scaling, SURVEY.md section 6)"},
+    }
+    stat = float(np.sqrt(((gpu_frame_rows(lrows).astype(np.float64) - lframe[lrows]) ** 2).mean()))
+    rmse = {"same_stream": exact, "same_stream_rows": len(rows),
+            "libc_random_stream": stat, "libc_random_rows": len(lrows), "unit": "8-bit levels"}
+    return out, rmse
+
+
+def read_profiled_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary, if any."""
+    p = ROOT / "profiles" / "hbm_traffic.json"
+    try:
+        data = json.loads(p.read_text())
+        return data.get(workload, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run "
+                             "(one process per GPU)")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    import path_tracer_c_amd as pt
+    from path_tracer_c_amd import tiles
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    pt._abi.check(pt.lib().ptgpu_set_device(local_rank))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = dict(pt.CONFIGS[int(args.workload[1])])
+    if args.spp:
+        cfg["spp"] = args.spp
+    w, h = cfg["width"], cfg["height"]
+    progressive = args.workload == "c3"
+    pass_spp = min(args.pass_spp, cfg["spp"]) if progressive else cfg["spp"]
+    n_pass = cfg["spp"] // pass_spp if progressive else 1
+
+    scene = pt.HostScene(cfg["scene"])
+    n_sph, n_tri = scene.counts()
+    dscene = pt.DeviceScene(scene)               # scene resident in HBM before timing
+    stream = torch.cuda.current_stream().cuda_stream
+
+    tile = args.tile_rows or tiles.default_tile_rows(h, world)
+    shard = tiles.shard_rows(h, world, rank, tile)
+    pad_rows = tiles.max_shard_rows(h, world, tile)
+    flags = args.flags | (pt._abi.FLAG_COMPACT_ROWS if world > 1 else 0)
+    base = dict(max_bounces=cfg["max_bounces"], seed=cfg["seed"], row_begin=shard.row_begin,
+                num_rows=shard.num_rows, tile_rows=shard.tile_rows if world > 1 else 0,
+                tile_stride=shard.tile_stride, flags=flags, block_threads=args.block)
+    local = torch.zeros((pad_rows, w, 3), dtype=torch.uint8, device="cuda")
+    accum = torch.zeros((pad_rows, w, 4), dtype=torch.float32, device="cuda") if progressive else None
+    frame = local
+    if world > 1:
+        parts = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+        index = [torch.tensor(tiles.shard_rows(h, world, r, tile).global_rows(),
+                              dtype=torch.long, device="cuda") for r in range(world)] if rank == 0 else None
+        frame = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda") if rank == 0 else None
+
+    kernel_ms = []
+
+    def step(timed):
+        """One frame: render this rank's rows (+ gather at N > 1)."""
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        if progressive:
+            accum.zero_()
+            for k in range(n_pass):
+                p = pt.make_params(spp=pass_spp, sample_offset=k * pass_spp,
+                                   **{**base, "flags": base["flags"] | pt._abi.FLAG_COMPACT_ROWS})
+                dscene.accumulate(accum.data_ptr(), w, h, p, stream)
+            pt.host.resolve(accum.data_ptr(), local.data_ptr(), shard.num_rows * w, stream)
+        else:
+            p = pt.make_params(spp=cfg["spp"], **base)
+            dscene.render(local.data_ptr(), w, h, p, stream)
+        ev1.record()
+        if world > 1:
+            dist.gather(local, gather_list=parts, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    frame.index_copy_(0, index[r], parts[r][: index[r].numel()])
+        if timed:
+            kernel_ms.append((ev0, ev1))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    pt.host.reset_stats()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    st = pt.host.read_stats()
+    counts = torch.tensor([st.rays, st.samples, st.wave_iters], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    kmax = torch.tensor([sum(a.elapsed_time(b) for a, b in kernel_ms) / max(1, len(kernel_ms))],
+                        dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+    rays, samples, wave_iters = (float(x) for x in counts.tolist())
+    elapsed = float(tmax.item())
+    kernel_ms_avg = float(kmax.item())
+
+    if rank == 0:
+        rays_per_step = rays / args.steps
+        launches_per_step = n_pass
+        fpr = flop_per_ray(n_sph, n_tri)
+        # per-GPU kernel: this rank's share of the rays over its kernel time
+        rays_per_launch = rays_per_step / world / launches_per_step
+        k_s = kernel_ms_avg * 1e-3 / launches_per_step
+        achieved_tflops = rays_per_launch * fpr / k_s / 1e12
+        if progressive:   # read + write one float4 per pixel per pass
+            hbm_alg = 32.0 * shard.num_rows * w
+        else:             # 3 bytes per pixel, once
+            hbm_alg = 3.0 * shard.num_rows * w
+        line = {
+            "metric": METRIC,
+            "value": rays / elapsed / 1e6,
+            "unit": "Mray/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE config {args.workload[1]}: scene {cfg['scene']} "
+                            f"({n_sph} spheres, {n_tri} triangles), {w}x{h}, {cfg['spp']} spp, "
+                            f"{cfg['max_bounces']} bounces, seed {cfg['seed']}"
+                            + (f", {n_pass} progressive passes of {pass_spp} spp" if progressive else ""),
+                "sharding": "single launch" if world == 1 else
+                            f"{tile}-row tiles interleaved over {world} ranks + one RCCL gather",
+                "rays_per_sample": rays / samples if samples else None,
+                "msample_per_s": samples / elapsed / 1e6,
+                "lane_utilisation": rays / (64.0 * wave_iters) if wave_iters else None,
+            },
+            "roofline": {
+                "kernel": "pt_megakernel",
+                "bound": "valu",
+                "achieved": achieved_tflops,
+                "peak": PEAK_FP32_VECTOR_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved_tflops / PEAK_FP32_VECTOR_TFLOPS,
+                "flop_per_ray": fpr,
+                "rays_per_launch": rays_per_launch,
+                "kernel_ms": kernel_ms_avg / launches_per_step,
+                "note": "FP32 vector ALU roof (SURVEY.md 8(d)): no MFMA on this path and HBM "
+                        "is not binding; peak = packed-FP32 vector figure of "
+                        "MI355X_MICROARCH.md (78.6 TFLOP/s without v_pk_fma_f32)",
+                "traffic": read_profiled_traffic(args.workload),
+                "hbm": {"algorithmic_bytes_per_launch": hbm_alg,
+                        "achieved": hbm_alg / k_s / 1e9, "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": hbm_alg / k_s / 1e9 / PEAK_HBM_GBS},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            host_frame = frame.cpu().numpy()
+            base_line, rmse = cpu_baseline(pt, scene, cfg, lambda rows: host_frame[rows])
+            line["cpu_baseline"] = base_line
+            line["rmse_vs_cpu_ref"] = rmse
+        if args.out and frame is not None:
+            pt.host.write_bitmap(args.out, frame.cpu().numpy())
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,7 +14,9 @@ include/threadpool.h:6-13 of the reference) via include/path_tracer_api.h.
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
@@ -205,6 +207,30 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """libptgpu.so needs libamdhip64.so.7.  PyTorch-ROCm wheels bundle their
+    own copy under torch/lib with the same SONAME; a process that loaded the
+    system copy first leaves torch with a mismatched runtime
+    (torch.cuda.is_available() turns False).  So, when torch is installed,
+    load ITS copy first -- without importing torch -- and let the dynamic
+    linker resolve libptgpu.so's dependency to it.  Either import order then
+    works and both sides share one HIP runtime, streams and allocations."""
+    if "torch" in sys.modules:
+        return  # torch's runtime is already the one in the process
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    bundled = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if bundled.exists():
+        try:
+            C.CDLL(os.fspath(bundled), mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # fall back to the system runtime via libptgpu.so's NEEDED
+
+
 class PtgpuError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"ptgpu error {code}: {message}")
@@ -219,6 +245,7 @@ def lib() -> C.CDLL:
             raise OSError(
                 f"{LIB_PATH} is missing: run `make` (or __graft_entry__.build()); "
                 "there is no Python or CPU fallback for the render path")
+        _share_hip_runtime_with_torch()
         handle = C.CDLL(os.fspath(LIB_PATH))
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if a symbol is missing

@@ -1,0 +1,343 @@
+"""Parity of the HIP render path with the CPU oracle, through the C-ABI.
+
+Bar (integer/byte output, and the float accumulators too): BIT-EXACT on the
+same sample stream.  The kernel is compiled with -ffp-contract=off and
+correctly rounded sqrt/divide, and evaluates incident_light in the
+reference's recursion order, so there is no float tolerance to state for the
+exact-stream comparisons.  The one statistical comparison (GPU xorshift
+stream vs the reference's glibc random() stream) states its tolerance inline.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+f32 = np.float32
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+# ---- committed fixtures ---------------------------------------------------------
+@pytest.mark.parametrize("flags", [0, 0x2, 0x4], ids=["lds", "global", "tree"])
+@pytest.mark.parametrize("name", ["c1_64x64", "demo_80x50", "c2_96x54", "c5_48x27"])
+def test_golden_frames(gpu, name, flags):
+    z = np.load(GOLDEN / f"frame_{name}.npz")
+    cfg, w, h, spp, b, seed, rays = (int(v) for v in z["meta"])
+    gpu.host.reset_stats()
+    with gpu.HostScene(cfg) as s:
+        frame = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=seed, flags=flags)
+    assert np.array_equal(frame, z["frame"])
+    st = gpu.host.read_stats()
+    assert st.rays == rays and st.samples == w * h * spp   # exact ray accounting
+
+
+@pytest.mark.parametrize("cfg", [0, 2])
+def test_golden_rays(gpu, cfg):
+    z = np.load(GOLDEN / f"rays_cfg{cfg}.npz")
+    with gpu.HostScene(cfg) as s:
+        dist, point, normal, mat = gpu.trace_rays(s, z["origins"], z["directions"])
+    hit = z["distance"] >= 0
+    assert np.array_equal(bits(dist), bits(z["distance"]))
+    assert np.array_equal(bits(point[hit]), bits(z["point"][hit]))
+    assert np.array_equal(bits(normal[hit]), bits(z["normal"][hit]))
+    assert np.array_equal(mat[hit].astype(np.int64), z["material"][hit])
+
+
+# ---- seeded sweeps against the oracle ------------------------------------------------
+@pytest.mark.parametrize("cfg,w,h,spp,b", [
+    (1, 256, 256, 16, 4),      # BASELINE config 1, full size
+    (0, 160, 100, 16, 4),      # the reference's demo scene (spheres + triangles + glass)
+    (2, 192, 108, 32, 8),
+    (5, 96, 54, 8, 8),
+    (2, 64, 36, 3, 0),         # max_bounces 0: one ray per sample
+    (1, 101, 37, 5, 4),        # odd width: byte-store fallback, ragged last workgroup
+    (0, 1, 1, 7, 4),           # a single pixel
+    (5, 33, 9, 2, 20),         # deep bounce stack
+])
+@pytest.mark.parametrize("block", [64, 256, 1024])
+def test_frames_bit_equal_to_oracle(gpu, oracle, cfg, w, h, spp, b, block):
+    with gpu.HostScene(cfg) as s:
+        got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=21, block_threads=block)
+        ref, _ = oracle.render_rows(s, w, h, spp=spp, max_bounces=b, seed=21)
+    assert np.array_equal(got, ref)
+
+
+def test_random_rays_bit_equal_to_oracle(gpu, oracle):
+    rng = np.random.default_rng(5)
+    n = 50000
+    for cfg in (0, 1, 2, 5):
+        o = rng.uniform(-3, 3, (n, 3)).astype(f32)
+        d = rng.normal(size=(n, 3)).astype(f32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True).astype(f32)
+        with gpu.HostScene(cfg) as s:
+            g = gpu.trace_rays(s, o, d)
+            c = oracle.trace_rays(s, o, d)
+        hit = c[0] >= 0
+        assert hit.sum() > 1000
+        assert np.array_equal(bits(g[0]), bits(c[0]))
+        assert np.array_equal(bits(g[1][hit]), bits(c[1][hit]))
+        assert np.array_equal(bits(g[2][hit]), bits(c[2][hit]))
+        assert np.array_equal(g[3][hit], c[3][hit])
+
+
+def test_legacy_trace_ray_single_query(gpu, oracle):
+    V = gpu._abi.Vec3
+    with gpu.HostScene(0) as s:
+        hit = gpu.lib().trace_ray(V(0, 0, 0), V(0, 0, 1), s.ptr())
+        ref = oracle.lib().oracle_trace_ray(V(0, 0, 0), V(0, 0, 1), s.ptr())
+        miss = gpu.lib().trace_ray(V(0, 0, 0), V(0, 1, 0), s.ptr())
+    assert hit.distance == ref.distance > 0 and hit.material == ref.material
+    assert hit.point.tuple() == ref.point.tuple() and hit.normal.tuple() == ref.normal.tuple()
+    assert miss.distance == -1.0
+
+
+# ---- edge cases -------------------------------------------------------------------------
+def test_empty_scene_renders_the_sky(gpu):
+    with gpu.HostScene() as s:
+        s.set_sky(135.0 / 255.0, 206.0 / 255.0, 235.0 / 255.0)
+        frame = gpu.render_frame(s, 70, 20, spp=16)
+    assert (frame.reshape(-1, 3) == np.array([135, 206, 235], dtype=np.uint8)).all()
+
+
+def test_triangle_only_scene(gpu, oracle):
+    with gpu.HostScene() as s:
+        s.set_sky(0.1, 0.2, 0.3)
+        m = s.add_material((0.9, 0.8, 0.7), roughness=0.6)
+        e = s.add_material((0, 0, 0), emission_color=(1, 0.5, 0.25), emission_strength=2.0)
+        s.add_triangle((-5, -1, 0), (5, -1, 0), (0, -1, 12), m)
+        s.add_triangle((-2, 3, 6), (2, 3, 6), (0, 0.5, 7), e)
+        got = gpu.render_frame(s, 96, 64, spp=8, max_bounces=5, seed=2)
+        ref, _ = oracle.render_rows(s, 96, 64, spp=8, max_bounces=5, seed=2)
+    assert np.array_equal(got, ref) and got.std() > 0
+
+
+def test_scene_larger_than_lds_falls_back_to_global_scan(gpu, oracle):
+    rng = np.random.default_rng(1)
+    with gpu.HostScene() as s:
+        s.set_sky(0.5, 0.6, 0.7)
+        mats = [s.add_material(tuple(rng.uniform(0.2, 0.9, 3)), roughness=float(rng.uniform(0, 1)))
+                for _ in range(8)]
+        for _ in range(9000):                      # 9000 * 20 B > 160 KiB of LDS
+            c = (rng.uniform(-30, 30), rng.uniform(-10, 10), rng.uniform(5, 80))
+            s.add_sphere(c, float(rng.uniform(0.1, 0.6)), mats[int(rng.integers(8))])
+        got = gpu.render_frame(s, 48, 27, spp=2, max_bounces=3, seed=4)
+        ref, _ = oracle.render_rows(s, 48, 27, spp=2, max_bounces=3, seed=4)
+    assert np.array_equal(got, ref)
+
+
+def test_branching_material_uses_the_tree_kernel(gpu, oracle):
+    with gpu.HostScene(0) as s:                    # demo scene + a half-transparent ball
+        half = s.add_material((0.9, 0.9, 1.0), roughness=0.1, transparency=0.5)
+        frost = s.add_material((1.0, 0.8, 0.8), roughness=0.4, transparency=0.25,
+                               emission_color=(0.2, 0.1, 0.1), emission_strength=1.0)
+        s.add_sphere((0.3, 0.0, 3.0), 0.6, half)
+        s.add_sphere((-0.9, -0.5, 2.5), 0.4, frost)
+        with gpu.DeviceScene(s) as d:
+            assert d.branching
+        got = gpu.render_frame(s, 120, 75, spp=6, max_bounces=5, seed=8)
+        ref, rays = oracle.render_rows(s, 120, 75, spp=6, max_bounces=5, seed=8)
+    assert np.array_equal(got, ref)
+    assert rays > 120 * 75 * 6 * 2
+
+
+def test_nan_and_out_of_range_transparency(gpu, oracle):
+    with gpu.HostScene(1) as s:
+        weird = s.add_material((1, 1, 1), roughness=0.2, transparency=float("nan"))
+        neg = s.add_material((0.8, 0.8, 0.2), roughness=0.2, transparency=-0.5)
+        big = s.add_material((0.2, 0.8, 0.8), roughness=0.0, transparency=2.0)
+        s.add_sphere((-1.5, 0.5, 3), 0.5, weird)
+        s.add_sphere((1.5, 0.5, 3), 0.5, neg)
+        s.add_sphere((0.0, 1.2, 3), 0.4, big)
+        got = gpu.render_frame(s, 96, 96, spp=4, seed=6)
+        ref, _ = oracle.render_rows(s, 96, 96, spp=4, seed=6)
+    assert np.array_equal(got, ref)
+
+
+def test_limits_and_bad_arguments_are_reported(gpu):
+    A = gpu._abi
+    with gpu.HostScene(1) as s:
+        for kw, code in [(dict(max_bounces=63), A.PTGPU_ERR_LIMIT),
+                         (dict(max_bounces=15, flags=A.FLAG_FORCE_TREE), A.PTGPU_ERR_LIMIT),
+                         (dict(block_threads=100), A.PTGPU_ERR_INVALID),
+                         (dict(spp=0), A.PTGPU_ERR_INVALID),
+                         (dict(row_begin=64), A.PTGPU_ERR_INVALID),
+                         (dict(row_begin=60, num_rows=8), A.PTGPU_ERR_INVALID)]:
+            with pytest.raises(A.PtgpuError) as e:
+                gpu.render_frame(s, 64, 64, **kw)
+            assert e.value.code == code
+        s.c.objects[0].material = 99               # dangling material id
+        with pytest.raises(A.PtgpuError) as e:
+            gpu.render_frame(s, 8, 8)
+        assert e.value.code == A.PTGPU_ERR_INVALID
+
+
+def test_same_seed_same_bytes_other_seed_other_bytes(gpu):
+    with gpu.HostScene(2) as s:
+        a = gpu.render_frame(s, 128, 72, spp=8, max_bounces=8, seed=1)
+        b = gpu.render_frame(s, 128, 72, spp=8, max_bounces=8, seed=1)
+        c = gpu.render_frame(s, 128, 72, spp=8, max_bounces=8, seed=2)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+# ---- statistical parity with the reference's random() stream ---------------------------
+def test_statistical_parity_with_libc_random(gpu, oracle):
+    """Tolerance: RMSE(GPU, CPU random()) <= 1.25 x
+    RMSE(CPU random() seed A, seed B); |mean difference| <= 0.25/255 of full
+    scale per channel, i.e. 0.25 in 8-bit units."""
+    rmse = lambda p, q: float(np.sqrt(((p.astype(np.float64) - q) ** 2).mean()))
+    for cfg, w, h, spp, b in [(1, 192, 192, 16, 4), (0, 160, 100, 16, 4)]:
+        with gpu.HostScene(cfg) as s:
+            g = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=99)
+            oracle.lib().oracle_srandom(1)
+            a, _ = oracle.render_rows(s, w, h, spp=spp, max_bounces=b, rng_mode=1)
+            oracle.lib().oracle_srandom(2)
+            c, _ = oracle.render_rows(s, w, h, spp=spp, max_bounces=b, rng_mode=1)
+        assert rmse(g, a) <= 1.25 * rmse(a, c)
+        for ch in range(3):
+            assert abs(g[..., ch].astype(np.float64).mean() - a[..., ch].astype(np.float64).mean()) <= 0.25
+
+
+# ---- the legacy call sequence (threadpool + render_task) -----------------------------------
+def test_threadpool_render_task_frame(gpu, oracle, monkeypatch):
+    monkeypatch.setenv("PTGPU_SPP", "8")
+    monkeypatch.setenv("PTGPU_BOUNCES", "5")
+    monkeypatch.setenv("PTGPU_SEED", "31")
+    with gpu.HostScene(0) as s:
+        got = gpu.host.render_frame_legacy(s, 96, 60)
+        ref, _ = oracle.render_rows(s, 96, 60, spp=8, max_bounces=5, seed=31)
+        # a ragged subset of rows, queued out of order
+        some = [59, 3, 4, 5, 30, 31, 0]
+        part = gpu.host.render_frame_legacy(s, 96, 60, rows=some)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(part[sorted(some)], ref[sorted(some)])
+    rest = np.ones(60, bool)
+    rest[some] = False
+    assert not part[rest].any()
+
+
+def test_render_task_called_directly_renders_one_row(gpu, oracle):
+    A = gpu._abi
+    with gpu.HostScene(1) as s:
+        frame = np.zeros((32, 48, 3), dtype=np.uint8)
+        args = A.RenderArgs(7, 48, 32, frame.ctypes.data_as(C.POINTER(C.c_uint8)), C.pointer(s.c))
+        gpu.lib().render_task(C.byref(args))
+        ref, _ = oracle.render_rows(s, 48, 32, 7, 8)       # reference defaults: 16 spp, 4 bounces
+    assert np.array_equal(frame[7], ref[7]) and not frame[:7].any() and not frame[8:].any()
+
+
+def test_threadpool_runs_foreign_tasks_and_waits_for_all(gpu):
+    A = gpu._abi
+    lib = gpu.lib()
+    seen = []
+    cb = A.TASK_FN(lambda arg: seen.append(arg))
+    pool = A.ThreadPool()
+    lib.threadpool_init(C.byref(pool), 3)
+    for i in range(1, 6):
+        lib.threadpool_add_task(C.byref(pool), C.cast(cb, C.c_void_p), C.c_void_p(i))
+    assert pool.tasks.size == 5                        # queued, public field
+    lib.threadpool_wait_for_tasks(C.byref(pool))
+    assert sorted(seen) == [1, 2, 3, 4, 5] and pool.tasks.size == 0
+    lib.threadpool_wait_for_tasks(C.byref(pool))        # nothing queued: returns at once
+    lib.threadpool_destroy(C.byref(pool))
+
+
+# ---- device-resident API: shards, progressive passes, full-size frames ----------------------
+@pytest.fixture(scope="module")
+def torch_cuda(gpu):
+    import torch
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    return torch
+
+
+def render_device(gpu, torch, dscene, w, h, **kw):
+    p = gpu.make_params(**kw)
+    rows = p.num_rows if (p.flags & 1) and p.num_rows else h
+    out = torch.zeros((rows, w, 3), dtype=torch.uint8, device="cuda")
+    dscene.render(out.data_ptr(), w, h, p, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("world,tile", [(2, 8), (4, 4), (8, 8), (3, 5)])
+def test_row_tile_shards_reassemble_to_the_one_gpu_frame(gpu, torch_cuda, world, tile):
+    """The frame does not depend on the number of GPUs or the tile size: each
+    rank's compact shard, un-interleaved, equals the single-launch frame."""
+    from path_tracer_c_amd import tiles
+    w, h = 160, 90
+    kw = dict(spp=8, max_bounces=8, seed=17)
+    with gpu.HostScene(2) as s, gpu.DeviceScene(s) as d:
+        full = render_device(gpu, torch_cuda, d, w, h, **kw)
+        frame = np.zeros_like(full)
+        for r in range(world):
+            sh = tiles.shard_rows(h, world, r, tile)
+            part = render_device(gpu, torch_cuda, d, w, h, row_begin=sh.row_begin,
+                                 num_rows=sh.num_rows, tile_rows=sh.tile_rows,
+                                 tile_stride=sh.tile_stride,
+                                 flags=gpu._abi.FLAG_COMPACT_ROWS, **kw)
+            frame[sh.global_rows()] = part[: sh.num_rows]
+    assert np.array_equal(frame, full)
+
+
+def test_progressive_passes_equal_one_pass(gpu, torch_cuda, oracle):
+    torch = torch_cuda
+    w, h = 96, 54
+    stream = torch.cuda.current_stream().cuda_stream
+    with gpu.HostScene(2) as s, gpu.DeviceScene(s) as d:
+        acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        for k in range(4):
+            d.accumulate(acc.data_ptr(), w, h, gpu.make_params(spp=6, sample_offset=6 * k,
+                                                               max_bounces=8, seed=3), stream)
+        out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+        gpu.host.resolve(acc.data_ptr(), out.data_ptr(), w * h, stream)
+        torch.cuda.synchronize()
+        one = render_device(gpu, torch, d, w, h, spp=24, max_bounces=8, seed=3)
+        ref = np.zeros((h, w, 4), dtype=f32)
+        oracle.accumulate_rows(s, ref, w, h, spp=24, max_bounces=8, seed=3)
+    assert np.array_equal(bits(acc.cpu().numpy()), bits(ref))   # float sums, bit for bit
+    assert np.array_equal(out.cpu().numpy(), one)
+
+
+def test_full_size_config2_rows_against_the_oracle(gpu, torch_cuda, oracle):
+    """BASELINE config 2 at full size (1920x1080, 256 spp, 8 bounces) on the
+    GPU; the oracle renders three of its rows (the stream is a function of the
+    global pixel index, so rows can be checked in isolation)."""
+    c = gpu.CONFIGS[2]
+    w, h = c["width"], c["height"]
+    kw = dict(spp=c["spp"], max_bounces=c["max_bounces"], seed=c["seed"])
+    gpu.host.reset_stats()
+    with gpu.HostScene(c["scene"]) as s, gpu.DeviceScene(s) as d:
+        frame = render_device(gpu, torch_cuda, d, w, h, **kw)
+        st = gpu.host.read_stats()
+        assert st.samples == w * h * c["spp"]
+        assert 8.0 < st.rays / st.samples <= 9.0
+        for y in (0, 611, 1079):
+            ref, _ = oracle.render_rows(s, w, h, y, y + 1, **kw)
+            assert np.array_equal(frame[y], ref[y]), f"row {y}"
+    # size-independent property: a second launch of only the lower half,
+    # written compactly, equals the lower half of the frame
+    with gpu.HostScene(c["scene"]) as s, gpu.DeviceScene(s) as d:
+        half = render_device(gpu, torch_cuda, d, w, h, row_begin=540, num_rows=540,
+                             flags=gpu._abi.FLAG_COMPACT_ROWS, **kw)
+    assert np.array_equal(half, frame[540:])
+
+
+def test_full_size_config5_rows_against_the_oracle(gpu, torch_cuda, oracle):
+    c = gpu.CONFIGS[5]
+    w, h = c["width"], c["height"]
+    kw = dict(max_bounces=c["max_bounces"], seed=c["seed"])
+    with gpu.HostScene(c["scene"]) as s, gpu.DeviceScene(s) as d:
+        # 16 spp keeps the 1001-sphere oracle rows to seconds
+        lds = render_device(gpu, torch_cuda, d, w, h, spp=16, **kw)
+        glob = render_device(gpu, torch_cuda, d, w, h, spp=16,
+                             flags=gpu._abi.FLAG_SCENE_GLOBAL, **kw)
+        ref, _ = oracle.render_rows(s, w, h, 400, 401, spp=16, **kw)
+    assert np.array_equal(lds, glob)                    # LDS tile == global scan
+    assert np.array_equal(lds[400], ref[400])
