@@ -16,7 +16,7 @@ CSRC     := $(PKG)/csrc
 BUILD    := build
 LIBDIR   := $(PKG)/lib
 
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off \
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize $(EXTRA_HIPFLAGS) \
             -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math \
             -Wall -Wno-unused-function -Iinclude -I$(CSRC)
 CFLAGS   := -std=gnu2x -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude

@@ -79,7 +79,11 @@ typedef struct ptgpu_params {
     uint32_t flags;         /* PTGPU_FLAG_* */
     uint32_t block_threads; /* work-items per workgroup: 0 (= 256), or a
                                multiple of 64 up to 1024 */
-    uint32_t reserved;
+    uint32_t settle_lanes;  /* scheduling only, never changes the image: how
+                               many lanes of a wavefront must have finished a
+                               sample before they settle it together.  0 =
+                               chosen from the scene size; 1 = per-lane path
+                               regeneration; 64 = sample-synchronous waves */
 } ptgpu_params;
 
 typedef struct ptgpu_stats {

@@ -138,7 +138,7 @@ class Params(C.Structure):
         ("tile_stride", C.c_uint32),
         ("flags", C.c_uint32),
         ("block_threads", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("settle_lanes", C.c_uint32),
     ]
 
 

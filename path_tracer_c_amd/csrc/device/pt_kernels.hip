@@ -105,70 +105,96 @@ __device__ __forceinline__ V3 shade_level(const F4 m0, const F4 m1, V3 child) {
 
 // ---------------------------------------------------------------------------
 // Non-branching paths: every material has transparency <= 0 or >= 1.
+//
+// Wave-level schedule.  Each pass of the loop has two stages:
+//   trace+shade  lanes that own a live ray scan the scene and shade the hit,
+//                which either yields the next ray or ends the path (the lane
+//                then PARKS with the value its deepest call returns);
+//   settle       when the ballot says every lane is parked, or at least
+//                `settle_lanes` of them are, all parked lanes together unwind
+//                their recursion, add the clamped sample and regenerate their
+//                next sample's primary ray.
+// settle_lanes = 1 is plain per-lane path regeneration; 64 is a sample-
+// synchronous wave.  The settle stage is the divergent, scene-independent part
+// of a pass (9 dependent LDS-gather levels at 8 bounces); batching it trades a
+// few idle lane-passes for running it with many lanes instead of one or two.
+// The host picks settle_lanes from the scene size (a pass over 1000 objects
+// dwarfs a settle; a pass over 8 does not).  The image does not depend on it.
 // ---------------------------------------------------------------------------
-template <class Acc>
 __device__ __forceinline__ void
 run_paths(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
           uint32_t stack_stride, V3 d0, uint32_t pixel, uint32_t spp, V3 sky,
-          Acc &sum, uint32_t &rays, uint32_t &iters) {
+          V3 &sum, uint32_t &rays, uint32_t &iters) {
     uint32_t s = 0;
     uint32_t depth = 0;
     V3 o = splat(0.0f);
     V3 d = d0;
+    V3 r = splat(0.0f);        // value returned by the deepest call, once parked
+    bool live = s < spp;       // owns a ray to trace
+    bool parked = false;       // path ended, waiting for the settle stage
     uint32_t rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset);
+    const uint32_t settle_lanes = a.settle_lanes;
 
-    while (s < spp) {
+    while (__any(live || parked)) {
         ++iters;
-        ++rays;
-        const Hit h = closest_hit(rec, o, d);
-
-        bool done;
-        V3 r;
-        if (h.distance < 0.0f) { // miss: this level returns the sky colour
-            r = sky;
-            done = true;
-        } else {
-            const Surface sf = surface_at(rec, o, d, h);
-            stack[depth * stack_stride] = (uint16_t)sf.material;
-            ++depth;
-            const F4 m0 = rec.mat[2 * sf.material + 0];
-            const float transparency = rec.mat[2 * sf.material + 1].w;
-
-            V3 deviation = rand_unit_sphere(rng) * m0.w; // roughness * 0.5
-            V3 n = normalize(sf.normal + deviation);
-
-            Bounce b;
-            if (transparency < 1.0f) {
-                b = reflect_ray(d, n, sf.point);
-            } else if (transparency > 0.0f) {
-                b = refract_ray(d, n, sf.point);
-            } else { // NaN transparency: neither branch is taken
-                b.has_child = false;
-                b.origin = o;
-                b.direction = d;
-            }
-            o = b.origin;
-            d = b.direction;
-            r = splat(0.0f);
-            done = !b.has_child;
-            if (!done && depth > a.max_bounces) {
-                // the child call has bounces > MAX_BOUNCES: sky, no trace
+        if (live) {
+            ++rays;
+            const Hit h = closest_hit(rec, o, d);
+            if (h.distance < 0.0f) { // miss: this level returns the sky colour
                 r = sky;
-                done = true;
+                live = false;
+            } else {
+                const Surface sf = surface_at(rec, o, d, h);
+                stack[depth * stack_stride] = (uint16_t)sf.material;
+                ++depth;
+                const F4 m0 = rec.mat[2 * sf.material + 0];
+                const float transparency = rec.mat[2 * sf.material + 1].w;
+
+                V3 deviation = rand_unit_sphere(rng) * m0.w; // roughness * 0.5
+                V3 n = normalize(sf.normal + deviation);
+
+                Bounce b;
+                if (transparency < 1.0f) {
+                    b = reflect_ray(d, n, sf.point);
+                } else if (transparency > 0.0f) {
+                    b = refract_ray(d, n, sf.point);
+                } else { // NaN transparency: neither branch is taken
+                    b.has_child = false;
+                    b.origin = o;
+                    b.direction = d;
+                }
+                o = b.origin;
+                d = b.direction;
+                r = splat(0.0f);
+                live = b.has_child;
+                if (live && depth > a.max_bounces) {
+                    // the child call has bounces > MAX_BOUNCES: sky, no trace
+                    r = sky;
+                    live = false;
+                }
             }
+            parked = !live;
         }
 
-        if (done) {
-            for (uint32_t k = depth; k-- > 0;) {
-                const uint32_t m = stack[k * stack_stride];
-                r = shade_level(rec.mat[2 * m + 0], rec.mat[2 * m + 1], r);
+        // settle stage, decided per wave from the ballots
+        const unsigned long long parked_mask = __ballot(parked);
+        const unsigned long long live_mask = __ballot(live);
+        if (parked_mask != 0ull &&
+            (live_mask == 0ull || (uint32_t)__popcll(parked_mask) >= settle_lanes)) {
+            if (parked) {
+                for (uint32_t k = depth; k-- > 0;) {
+                    const uint32_t m = stack[k * stack_stride];
+                    r = shade_level(rec.mat[2 * m + 0], rec.mat[2 * m + 1], r);
+                }
+                sum = sum + clamp01(r); // per-sample clamp, src/renderer.c:88
+                ++s;
+                depth = 0;
+                o = splat(0.0f);
+                d = d0;
+                rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset + s);
+                parked = false;
+                live = s < spp;
             }
-            sum = sum + clamp01(r); // per-sample clamp, src/renderer.c:88
-            ++s;
-            depth = 0;
-            o = splat(0.0f);
-            d = d0;
-            rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset + s);
         }
     }
 }
@@ -187,9 +213,8 @@ struct Frame {
     uint32_t awaiting_transmit; // 0: child in flight is the reflection
 };
 
-template <class Acc>
 __device__ void run_tree(const SceneRecords &rec, const LaunchArgs &a, V3 d0,
-                         uint32_t pixel, uint32_t spp, V3 sky, Acc &sum,
+                         uint32_t pixel, uint32_t spp, V3 sky, V3 &sum,
                          uint32_t &rays, uint32_t &iters) {
     Frame frames[kTreeFrames];
     for (uint32_t s = 0; s < spp; ++s) {

@@ -79,6 +79,7 @@ struct LaunchArgs {
     uint32_t spp, sample_offset, max_bounces, seed;
     float tan_half_fov;
     uint32_t scene_in_lds;
+    uint32_t settle_lanes; // parked lanes that trigger a settle stage (1..64)
 };
 
 } // namespace pt

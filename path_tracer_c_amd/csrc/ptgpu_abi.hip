@@ -138,6 +138,7 @@ int ptgpu_params_from_env(ptgpu_params *p) {
     env_u32("PTGPU_SEED", &p->seed);
     env_u32("PTGPU_BLOCK", &p->block_threads);
     env_u32("PTGPU_FLAGS", &p->flags);
+    env_u32("PTGPU_SETTLE", &p->settle_lanes);
     if (const char *deg = std::getenv("PTGPU_FOV_DEG")) {
         char *end = nullptr;
         double d = std::strtod(deg, &end);
@@ -288,6 +289,21 @@ int ptgpu_scene_is_branching(const ptgpu_scene *s) {
 // ---------------------------------------------------------------------------
 namespace {
 
+// Settle threshold from the scene size.  One pass of the bounce loop costs
+// about 80 VALU instructions per object scanned plus ~400 for shading; one
+// settle stage about 265 (at 8 bounces) whatever the lane count.  Parking f
+// lanes for a pass wastes f/64 of a pass; settling costs one settle stage:
+// settle as soon as f * pass >= 64 * settle.
+uint32_t auto_settle_lanes(const pt::SceneDesc &d) {
+    const double pass = 80.0 * (double)d.n_obj + 400.0;
+    double f = 64.0 * 265.0 / pass;
+    if (f < 1.0)
+        f = 1.0;
+    if (f > 64.0)
+        f = 64.0;
+    return (uint32_t)(f + 0.5);
+}
+
 // Validates a call and fills the launch block.  `dest_rows` is the number of
 // rows the destination buffer must hold.
 int prepare_launch(const ptgpu_scene *s, size_t framew, size_t frameh,
@@ -349,6 +365,9 @@ int prepare_launch(const ptgpu_scene *s, size_t framew, size_t frameh,
     a->seed = p->seed;
     a->tan_half_fov = tanf(p->fov_rad / 2.0f); // src/renderer.c:77
     a->scene_in_lds = (p->flags & PTGPU_FLAG_SCENE_GLOBAL) ? 0u : 1u;
+    if (p->settle_lanes > 64u)
+        return fail(PTGPU_ERR_INVALID, "settle_lanes must be 0..64");
+    a->settle_lanes = p->settle_lanes ? p->settle_lanes : auto_settle_lanes(s->desc);
     if (a->scene_in_lds &&
         pt::megakernel_lds_bytes(*a, b, *tree) > kLdsBudget)
         a->scene_in_lds = 0; // too large for one CU's LDS: scan from L2/HBM
