@@ -40,7 +40,7 @@ PT_HD bool ray_sphere(V3 o, V3 d, V3 c, float r2, float &t1, float &t2) {
     float dscr = r2 - dot(dp, dp);
     if (dscr < 0.0f)
         return false;
-    dscr = sqrtf(dscr);
+    dscr = sqrt_rn(dscr);
     float q = (ddp >= 0.0f) ? (ddp + dscr) : (ddp - dscr);
     float a = q;
     float b = (dpp - r2) / q;
@@ -62,7 +62,7 @@ PT_HD bool ray_triangle(V3 o, V3 d, V3 v0, V3 e1, V3 e2, float &dist) {
     float det = dot(e1, p);
     if (det > -eps && det < eps)
         return false;
-    float inv_det = 1.0f / det;
+    float inv_det = rcp_rn(det);
     V3 t = o - v0;
     float u = inv_det * dot(t, p);
     if (u < 0.0f || u > 1.0f)
