@@ -43,7 +43,8 @@ import numpy as np  # noqa: E402
 
 METRIC = "Mray/s at 1920x1080, 256 spp, 8 bounces; per-pixel RMSE vs CPU ref"
 # MI355X_MICROARCH.md, chip-level parameters: "Peak FP32 (vector) 157.3 TFLOPS"
-# (packed v_pk_fma_f32 issue; 78.6 TFLOP/s for plain v_fma_f32), HBM3E 8 TB/s.
+# (= 256 CUs x 4 SIMD-32 x 2 FLOP/FMA x 2.4 GHz; v_fma_f32 issues a wave64 in 2 cycles),
+# HBM3E 8 TB/s.
 PEAK_FP32_VECTOR_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
@@ -297,8 +298,8 @@ def main():
                 "rays_per_launch": rays_per_launch,
                 "kernel_ms": kernel_ms_avg / launches_per_step,
                 "note": "FP32 vector ALU roof (SURVEY.md 8(d)): no MFMA on this path and HBM "
-                        "is not binding; peak = packed-FP32 vector figure of "
-                        "MI355X_MICROARCH.md (78.6 TFLOP/s without v_pk_fma_f32)",
+                        "is not binding; peak = FP32 vector figure of "
+                        "MI355X_MICROARCH.md (256 CUs x 4 SIMD-32 x 2 FLOP x 2.4 GHz)",
                 "traffic": read_profiled_traffic(args.workload),
                 "hbm": {"algorithmic_bytes_per_launch": hbm_alg,
                         "achieved": hbm_alg / k_s / 1e9, "peak": PEAK_HBM_GBS,

@@ -49,11 +49,25 @@ extern "C" {
                                          stored at row i of the destination
                                          (a shard buffer) instead of at its
                                          global row (a full frame) */
-#define PTGPU_FLAG_SCENE_GLOBAL 0x2u  /* scan the scene from global memory
-                                         (L2/HBM) instead of the LDS copy */
+#define PTGPU_FLAG_SCENE_GLOBAL 0x2u  /* scheduling only: scan the scene records
+                                         from global memory with wave-uniform
+                                         scalar loads (constant cache / L2).
+                                         This is what is chosen when neither
+                                         SCENE flag is given: it measured
+                                         faster than the LDS copy on every
+                                         configuration */
+#define PTGPU_FLAG_SCENE_LDS 0x40u    /* scheduling only: stage the scene into
+                                         LDS once per workgroup and scan it
+                                         with broadcast LDS reads (falls back
+                                         to the global scan if it cannot fit) */
 #define PTGPU_FLAG_FORCE_TREE 0x4u    /* use the branching (tree) kernel even
                                          if no material needs it */
 #define PTGPU_FLAG_NO_RAY_COUNT 0x8u  /* skip the ray/sample counters */
+#define PTGPU_FLAG_SCAN_PLAIN 0x10u   /* scheduling only: test every object in
+                                         full (default for < 32 objects) */
+#define PTGPU_FLAG_SCAN_SCREENED 0x20u /* scheduling only: conservative screen
+                                         + per-lane queues (default for >= 32
+                                         objects); same image either way */
 
 /* limits */
 #define PTGPU_MAX_BOUNCES_PATH 62 /* non-branching kernel (LDS material stack) */
@@ -77,7 +91,8 @@ typedef struct ptgpu_params {
     uint32_t tile_rows;
     uint32_t tile_stride;
     uint32_t flags;         /* PTGPU_FLAG_* */
-    uint32_t block_threads; /* work-items per workgroup: 0 (= 256), or a
+    uint32_t block_threads; /* work-items per workgroup: 0 (= 64 for the
+                               global scan, 256 with the LDS copy), or a
                                multiple of 64 up to 1024 */
     uint32_t settle_lanes;  /* scheduling only, never changes the image: how
                                many lanes of a wavefront must have finished a

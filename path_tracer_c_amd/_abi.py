@@ -33,6 +33,9 @@ FLAG_COMPACT_ROWS = 0x1
 FLAG_SCENE_GLOBAL = 0x2
 FLAG_FORCE_TREE = 0x4
 FLAG_NO_RAY_COUNT = 0x8
+FLAG_SCAN_PLAIN = 0x10
+FLAG_SCENE_LDS = 0x40
+FLAG_SCAN_SCREENED = 0x20
 
 MAX_BOUNCES_PATH = 62
 MAX_BOUNCES_TREE = 14

@@ -121,10 +121,11 @@ __device__ __forceinline__ V3 shade_level(const F4 m0, const F4 m1, V3 child) {
 // The host picks settle_lanes from the scene size (a pass over 1000 objects
 // dwarfs a settle; a pass over 8 does not).  The image does not depend on it.
 // ---------------------------------------------------------------------------
+template <bool kScreen>
 __device__ __forceinline__ void
 run_paths(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
-          uint32_t stack_stride, V3 d0, uint32_t pixel, uint32_t spp, V3 sky,
-          V3 &sum, uint32_t &rays, uint32_t &iters) {
+          uint32_t stack_stride, const ScreenQueue queue, V3 d0, uint32_t pixel,
+          uint32_t spp, V3 sky, V3 &sum, uint32_t &rays, uint32_t &iters) {
     uint32_t s = 0;
     uint32_t depth = 0;
     V3 o = splat(0.0f);
@@ -139,7 +140,8 @@ run_paths(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
         ++iters;
         if (live) {
             ++rays;
-            const Hit h = closest_hit(rec, o, d);
+            const Hit h = kScreen ? closest_hit_screened(rec, o, d, queue)
+                                  : closest_hit(rec, o, d);
             if (h.distance < 0.0f) { // miss: this level returns the sky colour
                 r = sky;
                 live = false;
@@ -327,7 +329,7 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
     return v;
 }
 
-template <bool kLds, bool kTree>
+template <bool kLds, bool kTree, bool kScreen>
 __global__ void __launch_bounds__(1024) pt_megakernel(const LaunchArgs a) {
     extern __shared__ uint4 lds_dyn[]; // 16-byte aligned base
 
@@ -362,6 +364,12 @@ __global__ void __launch_bounds__(1024) pt_megakernel(const LaunchArgs a) {
         rec.meta = a.scene.meta;
     }
     uint16_t *stack = reinterpret_cast<uint16_t *>(lds_dyn + lds_used16) + tid;
+    // per-lane candidate queues of the screened scan sit behind the bounce
+    // stack (2 * nthreads * (max_bounces + 1) bytes, rounded to 16)
+    const uint32_t stack16 = (2u * nthreads * (a.max_bounces + 1u) + 15u) / 16u;
+    ScreenQueue queue;
+    queue.slot = reinterpret_cast<uint32_t *>(lds_dyn + lds_used16 + stack16) + tid;
+    queue.stride = nthreads;
     __syncthreads();
 
     // ---- which pixel is mine ------------------------------------------------
@@ -402,8 +410,8 @@ __global__ void __launch_bounds__(1024) pt_megakernel(const LaunchArgs a) {
     if (kTree)
         run_tree(rec, a, d0, pixel, spp, sky, sum, rays, iters);
     else
-        run_paths(rec, a, stack, nthreads, d0, pixel, spp, sky, sum, rays,
-                  iters);
+        run_paths<kScreen>(rec, a, stack, nthreads, queue, d0, pixel, spp, sky,
+                           sum, rays, iters);
 
     // ---- write back ------------------------------------------------------------
     if (a.accum != nullptr) {
@@ -538,11 +546,11 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------
 // Launchers (called from the C-ABI layer).
 // ---------------------------------------------------------------------------
-template <bool kLds, bool kTree>
+template <bool kLds, bool kTree, bool kScreen>
 static hipError_t launch_variant(const LaunchArgs &a, uint32_t grid,
                                  uint32_t block, size_t lds_bytes,
                                  hipStream_t stream) {
-    auto kernel = pt_megakernel<kLds, kTree>;
+    auto kernel = pt_megakernel<kLds, kTree, kScreen>;
     if (lds_bytes > 64u * 1024u) {
         hipError_t e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(kernel),
@@ -558,8 +566,11 @@ size_t megakernel_lds_bytes(const LaunchArgs &a, uint32_t block, bool tree) {
     size_t bytes = 0;
     if (a.scene_in_lds)
         bytes += scene_lds_bytes(a.scene.n_obj, a.scene.n_tri, a.scene.n_mat);
-    if (!tree)
-        bytes += (size_t)2 * block * ((size_t)a.max_bounces + 1u);
+    if (!tree) {
+        bytes += ((size_t)2 * block * ((size_t)a.max_bounces + 1u) + 15u) & ~(size_t)15u;
+        if (a.screened)
+            bytes += (size_t)4 * block * kScreenQueue;
+    }
     return (bytes + 15u) & ~(size_t)15u;
 }
 
@@ -570,11 +581,17 @@ hipError_t launch_megakernel(const LaunchArgs &a, uint32_t block, bool tree,
         return hipSuccess;
     const uint32_t grid = (uint32_t)((npix + block - 1) / block);
     const size_t lds = megakernel_lds_bytes(a, block, tree);
-    if (a.scene_in_lds)
-        return tree ? launch_variant<true, true>(a, grid, block, lds, stream)
-                    : launch_variant<true, false>(a, grid, block, lds, stream);
-    return tree ? launch_variant<false, true>(a, grid, block, lds, stream)
-                : launch_variant<false, false>(a, grid, block, lds, stream);
+    if (tree)
+        return a.scene_in_lds
+                   ? launch_variant<true, true, false>(a, grid, block, lds, stream)
+                   : launch_variant<false, true, false>(a, grid, block, lds, stream);
+    if (a.screened)
+        return a.scene_in_lds
+                   ? launch_variant<true, false, true>(a, grid, block, lds, stream)
+                   : launch_variant<false, false, true>(a, grid, block, lds, stream);
+    return a.scene_in_lds
+               ? launch_variant<true, false, false>(a, grid, block, lds, stream)
+               : launch_variant<false, false, false>(a, grid, block, lds, stream);
 }
 
 hipError_t launch_resolve(const float *accum, uint8_t *frame, uint64_t npixels,

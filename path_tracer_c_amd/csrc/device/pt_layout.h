@@ -7,7 +7,7 @@
 // hit (src/renderer.c:34).  Device layout instead, all 16-byte records:
 //
 //   geom[i]  float4   sphere  : centre.xyz, radius*radius
-//                     triangle: v0.xyz, bits(triangle ordinal k)
+//                     triangle: v0.xyz, bits(0x80000000 | triangle ordinal k)
 //   meta[i]  uint32   bit 31 = triangle, bits 0..30 = material index
 //   tri[3k..3k+2]     float4  edge1 = v1-v0 | edge2 = v2-v0 | unit normal
 //                     crossn(v0-v1, v0-v2) (src/ray.c:50-52), w unused
@@ -79,6 +79,7 @@ struct LaunchArgs {
     uint32_t spp, sample_offset, max_bounces, seed;
     float tan_half_fov;
     uint32_t scene_in_lds;
+    uint32_t screened;     // large scene: screen + per-lane queue (pt_trace.h)
     uint32_t settle_lanes; // parked lanes that trigger a settle stage (1..64)
 };
 

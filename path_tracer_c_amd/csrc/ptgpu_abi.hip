@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -204,8 +205,11 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
         const shape &o = host->objects[i];
         if (o.tag == 0) { // SPHERE
             const float r = o.sphere.radius;
+            float r2 = r * r;
+            if (r2 != r2) // NaN radius: keep it a NaN, but with the sign bit
+                r2 = std::numeric_limits<float>::quiet_NaN(); // clear (= sphere)
             geom[i] = pt::F4{o.sphere.center.x, o.sphere.center.y,
-                             o.sphere.center.z, r * r};
+                             o.sphere.center.z, r2};
             meta[i] = (uint32_t)o.material;
         } else { // TRIANGLE
             const pt::V3 v0 = to_v3(o.triangle.v0), v1 = to_v3(o.triangle.v1),
@@ -214,7 +218,8 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
             // glms_vec3_crossn(v0 - v1, v0 - v2), src/ray.c:50-52
             const pt::V3 n = pt::normalize(pt::cross(v0 - v1, v0 - v2));
             float kbits;
-            std::memcpy(&kbits, &k, sizeof kbits);
+            const uint32_t tagged = k | 0x80000000u; // sign bit = triangle
+            std::memcpy(&kbits, &tagged, sizeof kbits);
             geom[i] = pt::F4{v0.x, v0.y, v0.z, kbits};
             tri[3 * k + 0] = pt::F4{e1.x, e1.y, e1.z, 0.0f};
             tri[3 * k + 1] = pt::F4{e2.x, e2.y, e2.z, 0.0f};
@@ -344,7 +349,9 @@ int prepare_launch(const ptgpu_scene *s, size_t framew, size_t frameh,
     if (!*tree && p->max_bounces > PTGPU_MAX_BOUNCES_PATH)
         return fail(PTGPU_ERR_LIMIT, "max_bounces exceeds the kernel's limit");
 
-    uint32_t b = p->block_threads ? p->block_threads : 256u;
+    const bool want_lds = (p->flags & PTGPU_FLAG_SCENE_LDS) &&
+                          !(p->flags & PTGPU_FLAG_SCENE_GLOBAL);
+    uint32_t b = p->block_threads ? p->block_threads : (want_lds ? 256u : 64u);
     if (b % 64u != 0 || b > 1024u)
         return fail(PTGPU_ERR_INVALID,
                     "block_threads must be a multiple of 64, at most 1024");
@@ -364,7 +371,12 @@ int prepare_launch(const ptgpu_scene *s, size_t framew, size_t frameh,
     a->max_bounces = p->max_bounces;
     a->seed = p->seed;
     a->tan_half_fov = tanf(p->fov_rad / 2.0f); // src/renderer.c:77
-    a->scene_in_lds = (p->flags & PTGPU_FLAG_SCENE_GLOBAL) ? 0u : 1u;
+    a->scene_in_lds = want_lds ? 1u : 0u;
+    a->screened = (s->desc.n_obj >= 32u) ? 1u : 0u;
+    if (p->flags & PTGPU_FLAG_SCAN_PLAIN)
+        a->screened = 0u;
+    if (p->flags & PTGPU_FLAG_SCAN_SCREENED)
+        a->screened = 1u;
     if (p->settle_lanes > 64u)
         return fail(PTGPU_ERR_INVALID, "settle_lanes must be 0..64");
     a->settle_lanes = p->settle_lanes ? p->settle_lanes : auto_settle_lanes(s->desc);

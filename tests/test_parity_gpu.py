@@ -25,7 +25,9 @@ def bits(a):
 
 
 # ---- committed fixtures ---------------------------------------------------------
-@pytest.mark.parametrize("flags", [0, 0x2, 0x4], ids=["lds", "global", "tree"])
+@pytest.mark.parametrize("flags", [0, 0x40, 0x4, 0x44, 0x10, 0x20, 0x50, 0x60],
+                         ids=["default", "lds", "tree", "lds+tree", "plain", "screened",
+                              "lds+plain", "lds+screened"])
 @pytest.mark.parametrize("name", ["c1_64x64", "demo_80x50", "c2_96x54", "c5_48x27"])
 def test_golden_frames(gpu, name, flags):
     z = np.load(GOLDEN / f"frame_{name}.npz")
@@ -62,9 +64,11 @@ def test_golden_rays(gpu, cfg):
     (5, 33, 9, 2, 20),         # deep bounce stack
 ])
 @pytest.mark.parametrize("block", [64, 256, 1024])
-def test_frames_bit_equal_to_oracle(gpu, oracle, cfg, w, h, spp, b, block):
+@pytest.mark.parametrize("scene_flag", [0, 0x40], ids=["global", "lds"])
+def test_frames_bit_equal_to_oracle(gpu, oracle, cfg, w, h, spp, b, block, scene_flag):
     with gpu.HostScene(cfg) as s:
-        got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=21, block_threads=block)
+        got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=21, block_threads=block,
+                               flags=scene_flag)
         ref, _ = oracle.render_rows(s, w, h, spp=spp, max_bounces=b, seed=21)
     assert np.array_equal(got, ref)
 
@@ -118,7 +122,7 @@ def test_triangle_only_scene(gpu, oracle):
     assert np.array_equal(got, ref) and got.std() > 0
 
 
-def test_scene_larger_than_lds_falls_back_to_global_scan(gpu, oracle):
+def test_scene_larger_than_lds_falls_back_to_global_scan(gpu, oracle, flags=0x40):
     rng = np.random.default_rng(1)
     with gpu.HostScene() as s:
         s.set_sky(0.5, 0.6, 0.7)
@@ -127,7 +131,7 @@ def test_scene_larger_than_lds_falls_back_to_global_scan(gpu, oracle):
         for _ in range(9000):                      # 9000 * 20 B > 160 KiB of LDS
             c = (rng.uniform(-30, 30), rng.uniform(-10, 10), rng.uniform(5, 80))
             s.add_sphere(c, float(rng.uniform(0.1, 0.6)), mats[int(rng.integers(8))])
-        got = gpu.render_frame(s, 48, 27, spp=2, max_bounces=3, seed=4)
+        got = gpu.render_frame(s, 48, 27, spp=2, max_bounces=3, seed=4, flags=flags)
         ref, _ = oracle.render_rows(s, 48, 27, spp=2, max_bounces=3, seed=4)
     assert np.array_equal(got, ref)
 
@@ -176,6 +180,41 @@ def test_limits_and_bad_arguments_are_reported(gpu):
         with pytest.raises(A.PtgpuError) as e:
             gpu.render_frame(s, 8, 8)
         assert e.value.code == A.PTGPU_ERR_INVALID
+
+
+@pytest.mark.parametrize("settle", [1, 5, 64])
+@pytest.mark.parametrize("flags", [0x10, 0x20, 0x60], ids=["plain", "screened", "lds+screened"])
+def test_scheduling_knobs_never_change_the_image(gpu, oracle, flags, settle):
+    """settle_lanes and the scan variant are scheduling only."""
+    for cfg, w, h, spp, b in [(0, 96, 60, 6, 4), (5, 64, 36, 4, 8), (2, 64, 36, 4, 8)]:
+        with gpu.HostScene(cfg) as s:
+            got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=13, flags=flags,
+                                   settle_lanes=settle)
+            ref, _ = oracle.render_rows(s, w, h, spp=spp, max_bounces=b, seed=13)
+        assert np.array_equal(got, ref), (cfg, flags, settle)
+
+
+def test_screened_scan_with_many_triangles_and_nan_radius(gpu, oracle):
+    """Triangles are always queued by the screen; a NaN radius must stay a
+    sphere record (sign bit of r*r cleared at upload)."""
+    rng = np.random.default_rng(3)
+    with gpu.HostScene() as s:
+        s.set_sky(0.4, 0.5, 0.6)
+        mats = [s.add_material(tuple(rng.uniform(0.2, 0.9, 3)), roughness=float(rng.uniform(0, 1)))
+                for _ in range(5)]
+        for i in range(60):
+            c = rng.uniform(-4, 4, 3) + np.array([0, 0, 8])
+            if i % 3 == 0:
+                s.add_triangle(tuple(c), tuple(c + rng.uniform(-1, 1, 3)),
+                               tuple(c + rng.uniform(-1, 1, 3)), mats[i % 5])
+            else:
+                s.add_sphere(tuple(c), float(rng.uniform(0.2, 0.7)), mats[i % 5])
+        s.add_sphere((0, 0, 5), float("nan"), mats[0])
+        s.add_sphere((1, 1, 6), -0.5, mats[1])           # negative radius: r*r = 0.25
+        got = gpu.render_frame(s, 80, 60, spp=4, max_bounces=4, seed=5)
+        plain = gpu.render_frame(s, 80, 60, spp=4, max_bounces=4, seed=5, flags=0x10)
+        ref, _ = oracle.render_rows(s, 80, 60, spp=4, max_bounces=4, seed=5)
+    assert np.array_equal(got, ref) and np.array_equal(plain, ref)
 
 
 def test_same_seed_same_bytes_other_seed_other_bytes(gpu):
@@ -335,9 +374,9 @@ def test_full_size_config5_rows_against_the_oracle(gpu, torch_cuda, oracle):
     kw = dict(max_bounces=c["max_bounces"], seed=c["seed"])
     with gpu.HostScene(c["scene"]) as s, gpu.DeviceScene(s) as d:
         # 16 spp keeps the 1001-sphere oracle rows to seconds
-        lds = render_device(gpu, torch_cuda, d, w, h, spp=16, **kw)
+        lds = render_device(gpu, torch_cuda, d, w, h, spp=16, **kw)   # default: global scalar scan
         glob = render_device(gpu, torch_cuda, d, w, h, spp=16,
-                             flags=gpu._abi.FLAG_SCENE_GLOBAL, **kw)
+                             flags=gpu._abi.FLAG_SCENE_LDS, **kw)
         ref, _ = oracle.render_rows(s, w, h, 400, 401, spp=16, **kw)
-    assert np.array_equal(lds, glob)                    # LDS tile == global scan
+    assert np.array_equal(lds, glob)                    # global scan == LDS tile
     assert np.array_equal(lds[400], ref[400])
