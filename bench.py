@@ -63,6 +63,11 @@ def parse_args():
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--flags", type=lambda s: int(s, 0), default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo is a rehearsal mode for boxes with fewer GPUs than ranks: "
+                         "ranks share devices and the gather goes through host memory")
+    ap.add_argument("--verify", action="store_true",
+                    help="compare the (gathered) frame with a single-launch render (untimed)")
     ap.add_argument("--out", default="", help="write the last frame as BMP (rank 0)")
     return ap.parse_args()
 
@@ -160,11 +165,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    pt._abi.check(pt.lib().ptgpu_set_device(local_rank))
+    device = local_rank % torch.cuda.device_count() if args.backend == "gloo" else local_rank
+    torch.cuda.set_device(device)
+    pt._abi.check(pt.lib().ptgpu_set_device(device))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
 
     cfg = dict(pt.CONFIGS[int(args.workload[1])])
     if args.spp:
@@ -214,7 +223,14 @@ def main():
             dscene.render(local.data_ptr(), w, h, p, stream)
         ev1.record()
         if world > 1:
-            dist.gather(local, gather_list=parts, dst=0)
+            if args.backend == "nccl":
+                dist.gather(local, gather_list=parts, dst=0)
+            else:  # rehearsal: stage through host memory
+                host_parts = [torch.empty(local.shape, dtype=local.dtype) for _ in range(world)] if rank == 0 else None
+                dist.gather(local.cpu(), gather_list=host_parts, dst=0)
+                if rank == 0:
+                    for r in range(world):
+                        parts[r].copy_(host_parts[r])
             if rank == 0:
                 for r in range(world):
                     frame.index_copy_(0, index[r], parts[r][: index[r].numel()])
@@ -239,10 +255,11 @@ def main():
     elapsed = time.perf_counter() - t0
 
     st = pt.host.read_stats()
-    counts = torch.tensor([st.rays, st.samples, st.wave_iters], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    red = "cuda" if args.backend == "nccl" else "cpu"
+    counts = torch.tensor([st.rays, st.samples, st.wave_iters], dtype=torch.float64, device=red)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red)
     kmax = torch.tensor([sum(a.elapsed_time(b) for a, b in kernel_ms) / max(1, len(kernel_ms))],
-                        dtype=torch.float64, device="cuda")
+                        dtype=torch.float64, device=red)
     if world > 1:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -311,6 +328,14 @@ def main():
             base_line, rmse = cpu_baseline(pt, scene, cfg, lambda rows: host_frame[rows])
             line["cpu_baseline"] = base_line
             line["rmse_vs_cpu_ref"] = rmse
+        if args.verify and frame is not None:
+            # the assembled frame must equal a single-launch render on this GPU
+            check = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+            dscene.render(check.data_ptr(), w, h,
+                          pt.make_params(spp=cfg["spp"], max_bounces=cfg["max_bounces"],
+                                         seed=cfg["seed"]), stream)
+            torch.cuda.synchronize()
+            line["verified_equal_to_single_launch"] = bool(torch.equal(check, frame[:h]))
         if args.out and frame is not None:
             pt.host.write_bitmap(args.out, frame.cpu().numpy())
         print(json.dumps(line), flush=True)
