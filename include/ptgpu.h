@@ -69,6 +69,21 @@ extern "C" {
                                          + per-lane queues (default for >= 32
                                          objects); same image either way */
 
+#define PTGPU_FLAG_PIXEL_OWNER 0x80u   /* scheduling only: one work-item owns a
+                                         pixel for all its samples (one launch
+                                         per frame; best when every path has
+                                         about the same length) */
+#define PTGPU_FLAG_SAMPLE_QUEUE 0x100u /* scheduling only: persistent waves pull
+                                         (pixel, sample) paths from a queue and
+                                         a second kernel sums each pixel's
+                                         samples in order (best when path
+                                         lengths differ between pixels).  With
+                                         neither flag the library measures lane
+                                         utilisation on a scene's first large
+                                         render (that call synchronises the
+                                         stream once) and remembers the
+                                         choice in the ptgpu_scene. */
+
 /* limits */
 #define PTGPU_MAX_BOUNCES_PATH 62 /* non-branching kernel (LDS material stack) */
 #define PTGPU_MAX_BOUNCES_TREE 14 /* branching kernel (per-lane frame stack) */

@@ -35,6 +35,8 @@ FLAG_FORCE_TREE = 0x4
 FLAG_NO_RAY_COUNT = 0x8
 FLAG_SCAN_PLAIN = 0x10
 FLAG_SCENE_LDS = 0x40
+FLAG_PIXEL_OWNER = 0x80
+FLAG_SAMPLE_QUEUE = 0x100
 FLAG_SCAN_SCREENED = 0x20
 
 MAX_BOUNCES_PATH = 62

@@ -121,81 +121,117 @@ __device__ __forceinline__ V3 shade_level(const F4 m0, const F4 m1, V3 child) {
 // The host picks settle_lanes from the scene size (a pass over 1000 objects
 // dwarfs a settle; a pass over 8 does not).  The image does not depend on it.
 // ---------------------------------------------------------------------------
+// State of one lane's path.
+struct PathState {
+    V3 o, d;        // ray to trace next
+    V3 r;           // value returned by the deepest call, once parked
+    uint32_t depth; // hits recorded on the bounce stack so far
+    uint32_t rng;
+    bool live;      // owns a ray to trace
+    bool parked;    // path ended, waiting for the settle stage
+};
+
+// One recursion level of incident_light for a live lane: scan the scene, then
+// either end the path (miss, depth limit, total internal reflection) or
+// produce the next ray (src/renderer.c:24-70).
+template <bool kScreen>
+__device__ __forceinline__ void
+advance_path(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
+             uint32_t stack_stride, const ScreenQueue queue, V3 sky,
+             PathState &p) {
+    const Hit h = kScreen ? closest_hit_screened(rec, p.o, p.d, queue)
+                          : closest_hit(rec, p.o, p.d);
+    if (h.distance < 0.0f) { // miss: this level returns the sky colour
+        p.r = sky;
+        p.live = false;
+    } else {
+        const Surface sf = surface_at(rec, p.o, p.d, h);
+        stack[p.depth * stack_stride] = (uint16_t)sf.material;
+        ++p.depth;
+        const F4 m0 = rec.mat[2 * sf.material + 0];
+        const float transparency = rec.mat[2 * sf.material + 1].w;
+
+        V3 deviation = rand_unit_sphere(p.rng) * m0.w; // roughness * 0.5
+        V3 n = normalize(sf.normal + deviation);
+
+        Bounce b;
+        if (transparency < 1.0f) {
+            b = reflect_ray(p.d, n, sf.point);
+        } else if (transparency > 0.0f) {
+            b = refract_ray(p.d, n, sf.point);
+        } else { // NaN transparency: neither branch is taken
+            b.has_child = false;
+            b.origin = p.o;
+            b.direction = p.d;
+        }
+        p.o = b.origin;
+        p.d = b.direction;
+        p.r = splat(0.0f);
+        p.live = b.has_child;
+        if (p.live && p.depth > a.max_bounces) {
+            // the child call has bounces > MAX_BOUNCES: sky, no trace
+            p.r = sky;
+            p.live = false;
+        }
+    }
+    p.parked = !p.live;
+}
+
+// The unwind of a parked lane: re-apply Le + lerp(refl, trans, t) * albedo
+// from the deepest recorded level up; returns the clamped sample
+// (src/renderer.c:72-73, 88).
+__device__ __forceinline__ V3 unwind_path(const SceneRecords &rec,
+                                          const uint16_t *stack,
+                                          uint32_t stack_stride,
+                                          const PathState &p) {
+    V3 r = p.r;
+    for (uint32_t k = p.depth; k-- > 0;) {
+        const uint32_t m = stack[k * stack_stride];
+        r = shade_level(rec.mat[2 * m + 0], rec.mat[2 * m + 1], r);
+    }
+    return clamp01(r);
+}
+
+// Wave-uniform decision of the settle stage (see run_paths).
+__device__ __forceinline__ bool settle_now(bool live, bool parked,
+                                           uint32_t settle_lanes) {
+    const unsigned long long parked_mask = __ballot(parked);
+    const unsigned long long live_mask = __ballot(live);
+    return parked_mask != 0ull &&
+           (live_mask == 0ull || (uint32_t)__popcll(parked_mask) >= settle_lanes);
+}
+
 template <bool kScreen>
 __device__ __forceinline__ void
 run_paths(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
           uint32_t stack_stride, const ScreenQueue queue, V3 d0, uint32_t pixel,
           uint32_t spp, V3 sky, V3 &sum, uint32_t &rays, uint32_t &iters) {
     uint32_t s = 0;
-    uint32_t depth = 0;
-    V3 o = splat(0.0f);
-    V3 d = d0;
-    V3 r = splat(0.0f);        // value returned by the deepest call, once parked
-    bool live = s < spp;       // owns a ray to trace
-    bool parked = false;       // path ended, waiting for the settle stage
-    uint32_t rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset);
-    const uint32_t settle_lanes = a.settle_lanes;
+    PathState p;
+    p.o = splat(0.0f);
+    p.d = d0;
+    p.r = splat(0.0f);
+    p.depth = 0;
+    p.rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset);
+    p.live = s < spp;
+    p.parked = false;
 
-    while (__any(live || parked)) {
+    while (__any(p.live || p.parked)) {
         ++iters;
-        if (live) {
+        if (p.live) {
             ++rays;
-            const Hit h = kScreen ? closest_hit_screened(rec, o, d, queue)
-                                  : closest_hit(rec, o, d);
-            if (h.distance < 0.0f) { // miss: this level returns the sky colour
-                r = sky;
-                live = false;
-            } else {
-                const Surface sf = surface_at(rec, o, d, h);
-                stack[depth * stack_stride] = (uint16_t)sf.material;
-                ++depth;
-                const F4 m0 = rec.mat[2 * sf.material + 0];
-                const float transparency = rec.mat[2 * sf.material + 1].w;
-
-                V3 deviation = rand_unit_sphere(rng) * m0.w; // roughness * 0.5
-                V3 n = normalize(sf.normal + deviation);
-
-                Bounce b;
-                if (transparency < 1.0f) {
-                    b = reflect_ray(d, n, sf.point);
-                } else if (transparency > 0.0f) {
-                    b = refract_ray(d, n, sf.point);
-                } else { // NaN transparency: neither branch is taken
-                    b.has_child = false;
-                    b.origin = o;
-                    b.direction = d;
-                }
-                o = b.origin;
-                d = b.direction;
-                r = splat(0.0f);
-                live = b.has_child;
-                if (live && depth > a.max_bounces) {
-                    // the child call has bounces > MAX_BOUNCES: sky, no trace
-                    r = sky;
-                    live = false;
-                }
-            }
-            parked = !live;
+            advance_path<kScreen>(rec, a, stack, stack_stride, queue, sky, p);
         }
-
-        // settle stage, decided per wave from the ballots
-        const unsigned long long parked_mask = __ballot(parked);
-        const unsigned long long live_mask = __ballot(live);
-        if (parked_mask != 0ull &&
-            (live_mask == 0ull || (uint32_t)__popcll(parked_mask) >= settle_lanes)) {
-            if (parked) {
-                for (uint32_t k = depth; k-- > 0;) {
-                    const uint32_t m = stack[k * stack_stride];
-                    r = shade_level(rec.mat[2 * m + 0], rec.mat[2 * m + 1], r);
-                }
-                sum = sum + clamp01(r); // per-sample clamp, src/renderer.c:88
+        if (settle_now(p.live, p.parked, a.settle_lanes)) {
+            if (p.parked) {
+                sum = sum + unwind_path(rec, stack, stack_stride, p);
                 ++s;
-                depth = 0;
-                o = splat(0.0f);
-                d = d0;
-                rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset + s);
-                parked = false;
-                live = s < spp;
+                p.depth = 0;
+                p.o = splat(0.0f);
+                p.d = d0;
+                p.rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset + s);
+                p.parked = false;
+                p.live = s < spp;
             }
         }
     }
@@ -329,139 +365,343 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
     return v;
 }
 
-template <bool kLds, bool kTree, bool kScreen>
-__global__ void __launch_bounds__(1024) pt_megakernel(const LaunchArgs a) {
-    extern __shared__ uint4 lds_dyn[]; // 16-byte aligned base
+// ---- pieces shared by the kernels ---------------------------------------------
+struct WorkgroupScene {
+    SceneRecords rec;
+    uint16_t *stack;   // this lane's level-0 entry of the bounce stack
+    ScreenQueue queue; // this lane's candidate queue (screened scan)
+};
 
-    const uint32_t tid = threadIdx.x;
-    const uint32_t nthreads = blockDim.x;
-
-    // ---- stage the scene blob into LDS (once per workgroup) ---------------
+// Stage the scene blob into LDS (kLds) or point at global memory, and carve
+// the per-lane bounce stack and candidate queue out of dynamic LDS.
+template <bool kLds>
+__device__ __forceinline__ WorkgroupScene
+stage_scene(const LaunchArgs &a, uint4 *lds_dyn, uint32_t tid, uint32_t nthreads) {
+    WorkgroupScene w;
     const uint32_t n_obj = a.scene.n_obj;
     const uint32_t n_tri = a.scene.n_tri;
     const uint32_t n_mat = a.scene.n_mat;
-    const uint32_t blob16 =
-        (uint32_t)(scene_lds_bytes(n_obj, n_tri, n_mat) / 16u);
-
-    SceneRecords rec;
-    rec.n_obj = n_obj;
+    w.rec.n_obj = n_obj;
     uint32_t lds_used16 = 0;
     if (kLds) {
+        const uint32_t blob16 =
+            (uint32_t)(scene_lds_bytes(n_obj, n_tri, n_mat) / 16u);
         const uint4 *src = reinterpret_cast<const uint4 *>(a.scene.geom);
         for (uint32_t i = tid; i < blob16; i += nthreads)
             lds_dyn[i] = src[i];
         const F4 *base = reinterpret_cast<const F4 *>(lds_dyn);
-        rec.geom = base;
-        rec.tri = base + n_obj;
-        rec.mat = base + n_obj + 3u * n_tri;
-        rec.meta = reinterpret_cast<const uint32_t *>(base + n_obj + 3u * n_tri +
-                                                      2u * n_mat);
+        w.rec.geom = base;
+        w.rec.tri = base + n_obj;
+        w.rec.mat = base + n_obj + 3u * n_tri;
+        w.rec.meta = reinterpret_cast<const uint32_t *>(base + n_obj + 3u * n_tri +
+                                                        2u * n_mat);
         lds_used16 = blob16;
     } else {
-        rec.geom = a.scene.geom;
-        rec.tri = a.scene.tri;
-        rec.mat = a.scene.mat;
-        rec.meta = a.scene.meta;
+        w.rec.geom = a.scene.geom;
+        w.rec.tri = a.scene.tri;
+        w.rec.mat = a.scene.mat;
+        w.rec.meta = a.scene.meta;
     }
-    uint16_t *stack = reinterpret_cast<uint16_t *>(lds_dyn + lds_used16) + tid;
-    // per-lane candidate queues of the screened scan sit behind the bounce
-    // stack (2 * nthreads * (max_bounces + 1) bytes, rounded to 16)
+    w.stack = reinterpret_cast<uint16_t *>(lds_dyn + lds_used16) + tid;
+    // the candidate queues of the screened scan sit behind the bounce stack
+    // (2 * nthreads * (max_bounces + 1) bytes, rounded up to 16)
     const uint32_t stack16 = (2u * nthreads * (a.max_bounces + 1u) + 15u) / 16u;
-    ScreenQueue queue;
-    queue.slot = reinterpret_cast<uint32_t *>(lds_dyn + lds_used16 + stack16) + tid;
-    queue.stride = nthreads;
+    w.queue.slot =
+        reinterpret_cast<uint32_t *>(lds_dyn + lds_used16 + stack16) + tid;
+    w.queue.stride = nthreads;
     __syncthreads();
+    return w;
+}
 
-    // ---- which pixel is mine ------------------------------------------------
+// Where local pixel j of the call's row set lives, and its primary ray
+// (src/renderer.c:94-100, 76-85).
+struct PixelSite {
+    uint32_t pixel;     // global pixel index grow * W + sx: RNG stream + ray
+    uint64_t out_pixel; // index in the destination buffer
+    V3 d0;
+};
+
+__device__ __forceinline__ PixelSite pixel_site(const LaunchArgs &a, uint64_t j) {
+    PixelSite ps;
     const uint32_t W = a.framew;
-    const uint64_t npix = (uint64_t)a.num_rows * W;
-    const uint64_t j = (uint64_t)blockIdx.x * nthreads + tid;
-    const bool valid = j < npix;
-    const uint32_t lrow = valid ? (uint32_t)(j / W) : 0u;
-    const uint32_t sx = valid ? (uint32_t)(j - (uint64_t)lrow * W) : 0u;
+    const uint32_t lrow = (uint32_t)(j / W);
+    const uint32_t sx = (uint32_t)(j - (uint64_t)lrow * W);
     uint32_t grow = a.row_begin + lrow;
     if (a.tile_rows != 0u) {
         const uint32_t tile = lrow / a.tile_rows;
         grow = a.row_begin + tile * a.tile_rows * a.tile_stride +
                (lrow - tile * a.tile_rows);
     }
-    const uint32_t pixel = grow * W + sx; // global pixel index: RNG + ray
-    const uint64_t out_pixel = (uint64_t)(a.compact ? lrow : grow) * W + sx;
-
-    // ---- primary ray (src/renderer.c:94-100, 76-85) --------------------------
+    ps.pixel = grow * W + sx;
+    ps.out_pixel = (uint64_t)(a.compact ? lrow : grow) * W + sx;
     const float fw = (float)a.framew, fh = (float)a.frameh;
     const float aspect = fw / fh;
     const float x = (float)sx / fw * 2.0f - 1.0f;
     const float y = -((float)grow / fh * 2.0f - 1.0f);
-    const V3 d0 = normalize(
-        V3{x * a.tan_half_fov, y * a.tan_half_fov / aspect, 1.0f});
+    ps.d0 = normalize(V3{x * a.tan_half_fov, y * a.tan_half_fov / aspect, 1.0f});
+    return ps;
+}
+
+// result * (1.0f / NUM_SAMPLES * 255.0f), truncated (src/renderer.c:108-114),
+// stored as coalesced dwords when the wave's 64 pixels are 192 contiguous,
+// 4-byte aligned bytes, else as single bytes.
+__device__ __forceinline__ void store_rgb8(uint8_t *frame, V3 sum, float samples,
+                                           uint64_t out_pixel, bool valid,
+                                           uint32_t lane) {
+    const float scale = 1.0f / samples * 255.0f;
+    const V3 px = sum * scale;
+    const uint32_t r8 = (uint32_t)(uint8_t)px.x;
+    const uint32_t g8 = (uint32_t)(uint8_t)px.y;
+    const uint32_t b8 = (uint32_t)(uint8_t)px.z;
+    const uint32_t packed = r8 | (g8 << 8) | (b8 << 16);
+
+    const uint64_t first = __shfl(out_pixel, 0, 64);
+    const bool wave_dense =
+        __all(valid && out_pixel == first + lane) &&
+        ((reinterpret_cast<uintptr_t>(frame + 3u * first) & 3u) == 0u);
+    // dword k of the wave's 192 bytes = bytes 4k..4k+3 = tail of pixel 4k/3
+    // and head of the next one
+    const uint32_t p0 = (4u * lane) / 3u;
+    const uint32_t sh = 8u * (4u * lane - 3u * p0);
+    const uint32_t lo = __shfl(packed, (int)(p0 & 63u), 64);
+    const uint32_t hi = __shfl(packed, (int)((p0 + 1u) & 63u), 64);
+    if (wave_dense) {
+        if (lane < 48u) {
+            const uint64_t both = (uint64_t)lo | ((uint64_t)hi << 24);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(frame + 3u * first);
+            dst[lane] = (uint32_t)(both >> sh);
+        }
+    } else if (valid) {
+        uint8_t *dst = frame + 3u * out_pixel;
+        dst[0] = (uint8_t)r8;
+        dst[1] = (uint8_t)g8;
+        dst[2] = (uint8_t)b8;
+    }
+}
+
+__device__ __forceinline__ void count_wave(Counters *c, uint32_t rays,
+                                           uint32_t samples, uint32_t iters,
+                                           uint32_t lane) {
+    if (c == nullptr)
+        return;
+    const uint32_t wrays = wave_sum(rays);
+    const uint32_t wsamples = wave_sum(samples);
+    const uint32_t witers = wave_max(iters);
+    if (lane == 0u) {
+        atomicAdd(&c->rays, (unsigned long long)wrays);
+        atomicAdd(&c->samples, (unsigned long long)wsamples);
+        atomicAdd(&c->wave_iters, (unsigned long long)witers);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Kernel 1: one work-item per pixel (pixel-owner mode).
+// ---------------------------------------------------------------------------
+template <bool kLds, bool kTree, bool kScreen>
+__global__ void __launch_bounds__(1024) pt_megakernel(const LaunchArgs a) {
+    extern __shared__ uint4 lds_dyn[]; // 16-byte aligned base
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nthreads = blockDim.x;
+    const WorkgroupScene w = stage_scene<kLds>(a, lds_dyn, tid, nthreads);
+
+    const uint64_t npix = (uint64_t)a.num_rows * a.framew;
+    const uint64_t j = (uint64_t)blockIdx.x * nthreads + tid;
+    const bool valid = j < npix;
+    const PixelSite ps = pixel_site(a, valid ? j : 0u);
     const V3 sky = V3{a.scene.sky[0], a.scene.sky[1], a.scene.sky[2]};
 
     // ---- all samples of this pixel -----------------------------------------
     V3 sum = splat(0.0f);
     float had = 0.0f;
+    const uint64_t acc_at = a.accum_local ? j : ps.out_pixel;
     if (a.accum != nullptr && valid) {
-        const float4 prev = reinterpret_cast<const float4 *>(a.accum)[out_pixel];
+        const float4 prev = reinterpret_cast<const float4 *>(a.accum)[acc_at];
         sum = V3{prev.x, prev.y, prev.z};
         had = prev.w;
     }
     uint32_t rays = 0, iters = 0;
     const uint32_t spp = valid ? a.spp : 0u;
     if (kTree)
-        run_tree(rec, a, d0, pixel, spp, sky, sum, rays, iters);
+        run_tree(w.rec, a, ps.d0, ps.pixel, spp, sky, sum, rays, iters);
     else
-        run_paths<kScreen>(rec, a, stack, nthreads, queue, d0, pixel, spp, sky,
-                           sum, rays, iters);
+        run_paths<kScreen>(w.rec, a, w.stack, nthreads, w.queue, ps.d0, ps.pixel,
+                           spp, sky, sum, rays, iters);
 
     // ---- write back ------------------------------------------------------------
     if (a.accum != nullptr) {
         if (valid)
-            reinterpret_cast<float4 *>(a.accum)[out_pixel] =
+            reinterpret_cast<float4 *>(a.accum)[acc_at] =
                 make_float4(sum.x, sum.y, sum.z, had + (float)a.spp);
     } else {
-        // result * (1.0f / NUM_SAMPLES * 255.0f), truncated (renderer.c:108-114)
-        const float scale = 1.0f / (float)a.spp * 255.0f;
-        const V3 px = sum * scale;
-        const uint32_t r8 = (uint32_t)(uint8_t)px.x;
-        const uint32_t g8 = (uint32_t)(uint8_t)px.y;
-        const uint32_t b8 = (uint32_t)(uint8_t)px.z;
-        const uint32_t packed = r8 | (g8 << 8) | (b8 << 16);
+        store_rgb8(a.frame, sum, (float)a.spp, ps.out_pixel, valid, tid & 63u);
+    }
+    count_wave(a.counters, rays, spp, iters, tid & 63u);
+}
 
-        const uint32_t lane = tid & 63u;
-        const uint64_t first = __shfl(out_pixel, 0, 64);
-        const bool wave_dense =
-            __all(valid && out_pixel == first + lane) &&
-            ((reinterpret_cast<uintptr_t>(a.frame + 3u * first) & 3u) == 0u);
-        // dword k of the wave's 192 bytes = bytes 4k..4k+3 = tail of pixel
-        // 4k/3 and head of the next one
-        const uint32_t p0 = (4u * lane) / 3u;
-        const uint32_t sh = 8u * (4u * lane - 3u * p0);
-        const uint32_t lo = __shfl(packed, (int)(p0 & 63u), 64);
-        const uint32_t hi = __shfl(packed, (int)((p0 + 1u) & 63u), 64);
-        if (wave_dense) {
-            if (lane < 48u) {
-                const uint64_t both = (uint64_t)lo | ((uint64_t)hi << 24);
-                uint32_t *dst = reinterpret_cast<uint32_t *>(a.frame + 3u * first);
-                dst[lane] = (uint32_t)(both >> sh);
+// ---------------------------------------------------------------------------
+// Kernel 2: sample-queue mode.  The unit of work is one (pixel, sample) path.
+//
+// In pixel-owner mode a wave runs until its most expensive pixel has finished
+// all its samples; lanes whose pixels see the sky idle (configuration 5: 25 %
+// of all lane-passes).  Here every wave is a persistent worker: tasks are
+// numbered sample-major (t = sample * npix_pad + local pixel), handed out in
+// chunks of 64 from one global counter; inside a wave, the ballot of free
+// lanes and its prefix sum (popcount of the lower bits) give each free lane
+// the next task of the wave's current chunk, so a lane whose path ends is
+// refilled on the next pass and all 64 lanes stay live until the task pool is
+// dry.  A finished path stores its clamped sample (float4, 16 bytes) to
+// sample_buf[t]; pt_sum_kernel then adds each pixel's samples in sample order,
+// which keeps the image bit-identical to pixel-owner mode.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kChunkBatch = 32; // chunks of 64 tasks reserved per atomic
+
+// The scene arrays, the sample buffer and the chunk counter come in as separate
+// __restrict__ kernel arguments: this kernel stores to global memory inside
+// its loop, and without the no-alias guarantee the compiler must assume a
+// store may change the scene, which turns the wave-uniform scalar loads of
+// the object scan (s_load, constant cache) into 64-lane vector loads.
+template <bool kLds, bool kScreen>
+__global__ void __launch_bounds__(1024)
+    pt_samplekernel(const LaunchArgs a, const F4 *__restrict__ scene_geom,
+                    const F4 *__restrict__ scene_tri,
+                    const F4 *__restrict__ scene_mat,
+                    const uint32_t *__restrict__ scene_meta,
+                    float4 *__restrict__ out,
+                    uint32_t *__restrict__ chunk_counter) {
+    extern __shared__ uint4 lds_dyn[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nthreads = blockDim.x;
+    const uint32_t lane = tid & 63u;
+    WorkgroupScene w = stage_scene<kLds>(a, lds_dyn, tid, nthreads);
+    if (!kLds) {
+        w.rec.geom = scene_geom;
+        w.rec.tri = scene_tri;
+        w.rec.mat = scene_mat;
+        w.rec.meta = scene_meta;
+    }
+    const V3 sky = V3{a.scene.sky[0], a.scene.sky[1], a.scene.sky[2]};
+    const uint32_t npix = a.num_rows * a.framew;
+
+    // wave-uniform cursor: a wave reserves kChunkBatch chunks with one atomic
+    // (one global counter sustains only ~90 atomics per microsecond chip-wide;
+    // per-chunk atomics made the counter, not the ALUs, the bottleneck) and
+    // walks them one after the other
+    uint32_t chunk_pos = 64u, chunk_sample = 0u, chunk_j0 = 0u;
+    uint32_t next_chunk = 0u, chunk_limit = 0u;
+    bool pool_dry = false;
+
+    bool have = false; // this lane owns a task
+    uint32_t out_index = 0;
+    PathState p;
+    p.o = p.d = p.r = splat(0.0f);
+    p.depth = 0;
+    p.rng = 1u;
+    p.live = p.parked = false;
+    uint32_t rays = 0, iters = 0, done = 0;
+
+    for (;;) {
+        // ---- refill free lanes from the wave's chunk (ballot + prefix sum) ----
+        unsigned long long free_mask = __ballot(!have);
+        while (free_mask != 0ull && !pool_dry) {
+            if (chunk_pos >= 64u) {
+                if (next_chunk >= chunk_limit) {
+                    const int leader = __ffsll((long long)free_mask) - 1;
+                    uint32_t c = 0;
+                    if ((int)lane == leader)
+                        c = atomicAdd(chunk_counter, kChunkBatch);
+                    c = __shfl(c, leader, 64);
+                    if (c >= a.num_chunks) {
+                        pool_dry = true;
+                        break;
+                    }
+                    next_chunk = c;
+                    chunk_limit = c + kChunkBatch < a.num_chunks ? c + kChunkBatch
+                                                                 : a.num_chunks;
+                }
+                const uint32_t c = next_chunk++;
+                chunk_sample = c / a.chunks_per_sample;
+                chunk_j0 = (c - chunk_sample * a.chunks_per_sample) * 64u;
+                chunk_pos = 0u;
             }
-        } else if (valid) {
-            uint8_t *dst = a.frame + 3u * out_pixel;
-            dst[0] = (uint8_t)r8;
-            dst[1] = (uint8_t)g8;
-            dst[2] = (uint8_t)b8;
+            const uint32_t avail = 64u - chunk_pos;
+            const uint32_t rank =
+                (uint32_t)__popcll(free_mask & ((1ull << lane) - 1ull));
+            if (!have && rank < avail) {
+                const uint32_t j = chunk_j0 + chunk_pos + rank;
+                if (j < npix) { // else: padding slot of the last chunk of a sample
+                    const PixelSite ps = pixel_site(a, j);
+                    have = true;
+                    out_index = chunk_sample * a.npix_pad + j;
+                    p.o = splat(0.0f);
+                    p.d = ps.d0;
+                    p.r = splat(0.0f);
+                    p.depth = 0;
+                    p.rng = ptgpu_rng_seed(a.seed, ps.pixel,
+                                           a.sample_offset + chunk_sample);
+                    p.live = true;
+                    p.parked = false;
+                }
+            }
+            const uint32_t wanted = (uint32_t)__popcll(free_mask);
+            chunk_pos += wanted < avail ? wanted : avail;
+            free_mask = __ballot(!have);
+        }
+        if (__ballot(have) == 0ull)
+            break; // pool dry and every lane idle
+
+        // ---- one recursion level for the live lanes -------------------------------
+        ++iters;
+        if (p.live) {
+            ++rays;
+            advance_path<kScreen>(w.rec, a, w.stack, nthreads, w.queue, sky, p);
+        }
+
+        // ---- settle parked lanes: unwind, emit the sample, free the lane ----------
+        if (settle_now(p.live, p.parked, a.settle_lanes)) {
+            if (p.parked) {
+                const V3 sample = unwind_path(w.rec, w.stack, nthreads, p);
+                out[out_index] = make_float4(sample.x, sample.y, sample.z, 0.0f);
+                p.parked = false;
+                have = false;
+                ++done;
+            }
         }
     }
+    count_wave(a.counters, rays, done, iters, lane);
+}
 
-    // ---- statistics: one atomic per wave and counter --------------------------
-    if (a.counters != nullptr) {
-        const uint32_t wrays = wave_sum(rays);
-        const uint32_t wsamples = wave_sum(spp);
-        const uint32_t witers = wave_max(iters);
-        if ((tid & 63u) == 0u) {
-            atomicAdd(&a.counters->rays, (unsigned long long)wrays);
-            atomicAdd(&a.counters->samples, (unsigned long long)wsamples);
-            atomicAdd(&a.counters->wave_iters, (unsigned long long)witers);
+// Adds the `spp` buffered samples of each pixel, in sample order, onto the
+// pixel's running sum (src/renderer.c:103-107), then stores either the
+// accumulator (float4: sums + sample count) or, on a frame's last pass, RGB8.
+__global__ void __launch_bounds__(256) pt_sum_kernel(const LaunchArgs a) {
+    const uint32_t npix = a.num_rows * a.framew;
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = j < npix;
+    const PixelSite ps = pixel_site(a, valid ? j : 0u);
+    const float4 *buf = reinterpret_cast<const float4 *>(a.sample_buf);
+    float4 *acc = reinterpret_cast<float4 *>(a.accum);
+    // accum is addressed like the destination frame when it is the caller's
+    // (out_pixel), and by local pixel when it is the library's scratch
+    const uint64_t at = a.accum_local ? j : ps.out_pixel;
+
+    V3 sum = splat(0.0f);
+    float had = 0.0f;
+    if (valid && !a.first_pass) {
+        const float4 prev = acc[at];
+        sum = V3{prev.x, prev.y, prev.z};
+        had = prev.w;
+    }
+    if (valid) {
+        for (uint32_t s = 0; s < a.spp; ++s) {
+            const float4 v = buf[(uint64_t)s * a.npix_pad + j];
+            sum = sum + V3{v.x, v.y, v.z};
         }
+    }
+    if (a.frame != nullptr) {
+        store_rgb8(a.frame, sum, had + (float)a.spp, ps.out_pixel, valid,
+                   threadIdx.x & 63u);
+    } else if (valid) {
+        acc[at] = make_float4(sum.x, sum.y, sum.z, had + (float)a.spp);
     }
 }
 
@@ -592,6 +832,54 @@ hipError_t launch_megakernel(const LaunchArgs &a, uint32_t block, bool tree,
     return a.scene_in_lds
                ? launch_variant<true, false, false>(a, grid, block, lds, stream)
                : launch_variant<false, false, false>(a, grid, block, lds, stream);
+}
+
+template <bool kLds, bool kScreen>
+static hipError_t launch_sample_variant(const LaunchArgs &a, uint32_t grid,
+                                        uint32_t block, size_t lds_bytes,
+                                        hipStream_t stream) {
+    auto kernel = pt_samplekernel<kLds, kScreen>;
+    if (lds_bytes > 64u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess)
+            return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds_bytes, stream, a,
+                       a.scene.geom, a.scene.tri, a.scene.mat, a.scene.meta,
+                       reinterpret_cast<float4 *>(a.sample_buf), a.chunk_counter);
+    return hipGetLastError();
+}
+
+hipError_t launch_samplekernel(const LaunchArgs &a, uint32_t block,
+                               uint32_t max_waves, hipStream_t stream) {
+    if (a.num_chunks == 0)
+        return hipSuccess;
+    // persistent workers: no more waves than the device keeps resident, and
+    // no more than there are chunks
+    const uint32_t waves_per_block = block / 64u;
+    uint64_t waves = a.num_chunks < max_waves ? a.num_chunks : max_waves;
+    uint32_t grid = (uint32_t)((waves + waves_per_block - 1) / waves_per_block);
+    if (grid == 0)
+        grid = 1;
+    const size_t lds = megakernel_lds_bytes(a, block, false);
+    if (a.screened)
+        return a.scene_in_lds
+                   ? launch_sample_variant<true, true>(a, grid, block, lds, stream)
+                   : launch_sample_variant<false, true>(a, grid, block, lds, stream);
+    return a.scene_in_lds
+               ? launch_sample_variant<true, false>(a, grid, block, lds, stream)
+               : launch_sample_variant<false, false>(a, grid, block, lds, stream);
+}
+
+hipError_t launch_sum(const LaunchArgs &a, hipStream_t stream) {
+    const uint64_t npix = (uint64_t)a.num_rows * a.framew;
+    if (npix == 0)
+        return hipSuccess;
+    const uint32_t grid = (uint32_t)((npix + 255u) / 256u);
+    hipLaunchKernelGGL(pt_sum_kernel, dim3(grid), dim3(256), 0, stream, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_resolve(const float *accum, uint8_t *frame, uint64_t npixels,

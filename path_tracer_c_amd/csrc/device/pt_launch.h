@@ -23,6 +23,11 @@ size_t megakernel_lds_bytes(const LaunchArgs &a, uint32_t block, bool tree);
 
 hipError_t launch_megakernel(const LaunchArgs &a, uint32_t block, bool tree,
                              hipStream_t stream);
+// Sample-queue mode: persistent waves pulling (pixel, sample) tasks, then the
+// ordered per-pixel sum.  `max_waves` = waves the device keeps resident.
+hipError_t launch_samplekernel(const LaunchArgs &a, uint32_t block,
+                               uint32_t max_waves, hipStream_t stream);
+hipError_t launch_sum(const LaunchArgs &a, hipStream_t stream);
 hipError_t launch_resolve(const float *accum, uint8_t *frame, uint64_t npixels,
                           hipStream_t stream);
 hipError_t launch_trace(const SceneDesc &scene, const float *origins,

@@ -81,6 +81,14 @@ struct LaunchArgs {
     uint32_t scene_in_lds;
     uint32_t screened;     // large scene: screen + per-lane queue (pt_trace.h)
     uint32_t settle_lanes; // parked lanes that trigger a settle stage (1..64)
+    // sample-queue mode (pt_samplekernel / pt_sum_kernel)
+    float *sample_buf;       // float4 per task: [sample][npix_pad]
+    uint32_t *chunk_counter; // next chunk of 64 tasks; zeroed before a launch
+    uint32_t npix_pad;       // pixels of the row set, rounded up to 64
+    uint32_t chunks_per_sample; // npix_pad / 64
+    uint32_t num_chunks;     // spp * chunks_per_sample
+    uint32_t first_pass;     // sum kernel: start from zero instead of accum
+    uint32_t accum_local;    // sum kernel: accum indexed by local pixel
 };
 
 } // namespace pt

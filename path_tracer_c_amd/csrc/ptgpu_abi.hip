@@ -97,6 +97,10 @@ struct ptgpu_scene {
     void *blob;          // one allocation: geom | tri | mat | meta
     size_t blob_bytes;
     pt::SceneDesc desc;  // device pointers into blob
+    // Which schedule suits this scene, measured on its first large render:
+    // -1 not measured yet, 0 pixel-owner kernel, 1 sample-queue kernels.
+    // Scheduling only; the image is the same.
+    mutable std::atomic<int> queue_mode{-1};
 };
 
 extern "C" {
@@ -407,25 +411,233 @@ void count_launch() {
 
 } // namespace
 
-int ptgpu_render_device(const ptgpu_scene *s, uint8_t *d_frame, size_t framew,
-                        size_t frameh, const ptgpu_params *p,
-                        void *hip_stream) {
-    if (d_frame == nullptr)
-        return fail(PTGPU_ERR_INVALID, "d_frame is NULL");
+namespace {
+
+// Per-device scratch of the sample-queue mode, grown on demand.
+struct DeviceScratch {
+    float *samples = nullptr;   // float4 per task of one pass
+    size_t sample_bytes = 0;
+    float *accum = nullptr;     // float4 per pixel (fused renders)
+    size_t accum_bytes = 0;
+    uint32_t *chunk_counters = nullptr; // ring of kCounterRing counters
+    uint32_t next_counter = 0;
+    uint32_t max_waves = 0;     // waves the device keeps resident
+};
+constexpr uint32_t kCounterRing = 256;
+DeviceScratch g_scratch[kMaxDevices];
+
+size_t scratch_budget_bytes() {
+    uint32_t mb = 2048; // sample buffer budget per device
+    env_u32("PTGPU_SCRATCH_MB", &mb);
+    if (mb < 64)
+        mb = 64;
+    return (size_t)mb << 20;
+}
+
+int grow(float **ptr, size_t *have, size_t need) {
+    if (*have >= need)
+        return PTGPU_OK;
+    PT_TRY_HIP(hipDeviceSynchronize()); // nothing may still be using the old one
+    if (*ptr)
+        (void)hipFree(*ptr);
+    *ptr = nullptr;
+    *have = 0;
+    PT_TRY_HIP(hipMalloc(ptr, need));
+    *have = need;
+    return PTGPU_OK;
+}
+
+int scratch_for_current_device(DeviceScratch **out) {
+    int dev = 0;
+    int rc = current_device(&dev);
+    if (rc != PTGPU_OK)
+        return rc;
+    DeviceScratch &sc = g_scratch[dev];
+    if (sc.chunk_counters == nullptr) {
+        PT_TRY_HIP(hipMalloc(&sc.chunk_counters, kCounterRing * sizeof(uint32_t)));
+        hipDeviceProp_t prop;
+        PT_TRY_HIP(hipGetDeviceProperties(&prop, dev));
+        const int per_cu = prop.maxThreadsPerMultiProcessor / 64;
+        sc.max_waves = (uint32_t)(prop.multiProcessorCount * (per_cu > 0 ? per_cu : 32));
+    }
+    *out = &sc;
+    return PTGPU_OK;
+}
+
+enum Mode { kPixelOwner = 0, kSampleQueue = 1 };
+
+// One frame's worth of work for both public entry points.  Exactly one of
+// `d_frame` (fused render: RGB8 out) and `d_accum` (caller's accumulator) is
+// non-null.  Every path below adds the samples of a pixel in sample order, so
+// they all produce the same bits; they differ in schedule only.
+int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
+                  size_t framew, size_t frameh, const ptgpu_params *p,
+                  hipStream_t stream) {
     pt::LaunchArgs a;
     uint32_t block = 0;
     bool tree = false;
     int rc = prepare_launch(s, framew, frameh, p, &a, &block, &tree);
     if (rc != PTGPU_OK)
         return rc;
-    a.frame = d_frame;
-    a.accum = nullptr;
-    hipError_t e =
-        pt::launch_megakernel(a, block, tree, (hipStream_t)hip_stream);
-    if (e != hipSuccess)
-        return fail_hip(e, "megakernel launch");
-    count_launch();
+    const uint64_t npix = (uint64_t)a.num_rows * a.framew;
+    const uint32_t total_spp = a.spp;
+
+    // ---- which schedule ------------------------------------------------------
+    int mode = s->queue_mode.load();
+    if (p->flags & PTGPU_FLAG_PIXEL_OWNER)
+        mode = kPixelOwner;
+    if (p->flags & PTGPU_FLAG_SAMPLE_QUEUE)
+        mode = kSampleQueue;
+    if (tree)
+        mode = kPixelOwner; // the branching kernel exists in pixel-owner form only
+    const bool can_measure = a.counters != nullptr && !tree && total_spp >= 16 &&
+                             npix * total_spp >= (1ull << 22);
+    if (mode < 0 && !can_measure)
+        mode = kPixelOwner;
+
+    if (mode == kPixelOwner && d_frame != nullptr) { // the one-launch fast path
+        a.frame = d_frame;
+        a.accum = nullptr;
+        hipError_t e = pt::launch_megakernel(a, block, tree, stream);
+        if (e != hipSuccess)
+            return fail_hip(e, "megakernel launch");
+        count_launch();
+        return PTGPU_OK;
+    }
+
+    // ---- everything else runs through an accumulator ----------------------------
+    DeviceScratch *sc = nullptr;
+    rc = scratch_for_current_device(&sc);
+    if (rc != PTGPU_OK)
+        return rc;
+    float *accum = d_accum;
+    a.accum_local = 0;
+    bool accum_is_zero = false; // scratch accumulator not written yet
+    if (d_frame != nullptr) {
+        rc = grow(&sc->accum, &sc->accum_bytes, (size_t)npix * 16u);
+        if (rc != PTGPU_OK)
+            return rc;
+        accum = sc->accum;
+        a.accum_local = 1;
+        accum_is_zero = true;
+    }
+    a.frame = nullptr;
+    a.accum = accum;
+    uint32_t done_spp = 0;
+
+    // ---- first large render of this scene: measure, then choose ----------------
+    // Pilot = the first samples, rendered in pixel-owner form (they count: the
+    // pilot is part of the frame).  It yields rays per sample and the lane
+    // utilisation of pixel-owner waves.  The queue schedule recovers the idle
+    // lane-passes (utilisation -> ~0.99) but moves 32 bytes per sample through
+    // HBM (store + ordered re-read), worth ~480 lane-instructions of a chip
+    // that issues ~6e13 of them per second against ~4 TB/s.  Take the queue
+    // when the recovered work per sample is clearly (2x) more than that.
+    if (mode < 0) {
+        const uint32_t pilot = total_spp / 2 < 16u ? total_spp / 2 : 16u;
+        pt::Counters before, after;
+        PT_TRY_HIP(hipStreamSynchronize(stream));
+        PT_TRY_HIP(hipMemcpy(&before, a.counters, sizeof before, hipMemcpyDeviceToHost));
+        if (accum_is_zero) {
+            PT_TRY_HIP(hipMemsetAsync(accum, 0, (size_t)npix * 16u, stream));
+            accum_is_zero = false;
+        }
+        pt::LaunchArgs q = a;
+        q.spp = pilot;
+        hipError_t e = pt::launch_megakernel(q, block, false, stream);
+        if (e != hipSuccess)
+            return fail_hip(e, "megakernel launch (pilot)");
+        count_launch();
+        PT_TRY_HIP(hipStreamSynchronize(stream));
+        PT_TRY_HIP(hipMemcpy(&after, a.counters, sizeof after, hipMemcpyDeviceToHost));
+        const double rays = (double)(after.rays - before.rays);
+        const double samples = (double)(after.samples - before.samples);
+        const double lane_passes = 64.0 * (double)(after.wave_iters - before.wave_iters);
+        const double util = lane_passes > 0 && rays > 0 ? rays / lane_passes : 1.0;
+        const double rays_per_sample = samples > 0 ? rays / samples : 1.0;
+        const double instr_per_ray =
+            (a.screened ? 16.0 : 80.0) * (double)a.scene.n_obj + 400.0;
+        const double recovered = (1.0 / util - 1.0 / 0.99) * rays_per_sample * instr_per_ray;
+        mode = recovered > 2.0 * 480.0 ? kSampleQueue : kPixelOwner;
+        s->queue_mode.store(mode);
+        done_spp = pilot;
+    }
+
+    if (mode == kPixelOwner) {
+        if (done_spp < total_spp) {
+            if (accum_is_zero) {
+                PT_TRY_HIP(hipMemsetAsync(accum, 0, (size_t)npix * 16u, stream));
+                accum_is_zero = false;
+            }
+            pt::LaunchArgs q = a;
+            q.spp = total_spp - done_spp;
+            q.sample_offset = a.sample_offset + done_spp;
+            hipError_t e = pt::launch_megakernel(q, block, tree, stream);
+            if (e != hipSuccess)
+                return fail_hip(e, "megakernel launch (accumulate)");
+            count_launch();
+        }
+        if (d_frame != nullptr) { // resolve the scratch accumulator
+            pt::LaunchArgs q = a;
+            q.spp = 0;
+            q.first_pass = 0;
+            q.frame = d_frame;
+            hipError_t e = pt::launch_sum(q, stream);
+            if (e != hipSuccess)
+                return fail_hip(e, "resolve launch");
+        }
+        return PTGPU_OK;
+    }
+
+    // ---- sample-queue passes -----------------------------------------------------
+    const uint32_t npix_pad = (uint32_t)((npix + 63u) & ~(uint64_t)63u);
+    uint64_t per_pass = scratch_budget_bytes() / ((uint64_t)npix_pad * 16u);
+    if (per_pass < 1)
+        per_pass = 1;
+    if (per_pass > total_spp - done_spp)
+        per_pass = total_spp - done_spp;
+    if ((uint64_t)npix_pad * per_pass > 0xFFFFFFFFull) // task ids are 32-bit
+        per_pass = 0xFFFFFFFFull / npix_pad;
+    rc = grow(&sc->samples, &sc->sample_bytes, (size_t)npix_pad * per_pass * 16u);
+    if (rc != PTGPU_OK)
+        return rc;
+    while (done_spp < total_spp) {
+        const uint32_t k = (uint32_t)(total_spp - done_spp < per_pass
+                                          ? total_spp - done_spp
+                                          : per_pass);
+        pt::LaunchArgs q = a;
+        q.spp = k;
+        q.sample_offset = a.sample_offset + done_spp;
+        q.sample_buf = sc->samples;
+        q.npix_pad = npix_pad;
+        q.chunks_per_sample = npix_pad / 64u;
+        q.num_chunks = k * q.chunks_per_sample;
+        q.chunk_counter = sc->chunk_counters + (sc->next_counter++ % kCounterRing);
+        PT_TRY_HIP(hipMemsetAsync(q.chunk_counter, 0, sizeof(uint32_t), stream));
+        hipError_t e = pt::launch_samplekernel(q, block, sc->max_waves, stream);
+        if (e != hipSuccess)
+            return fail_hip(e, "sample kernel launch");
+        count_launch();
+        done_spp += k;
+        q.first_pass = accum_is_zero ? 1u : 0u;
+        accum_is_zero = false;
+        q.frame = (d_frame != nullptr && done_spp == total_spp) ? d_frame : nullptr;
+        e = pt::launch_sum(q, stream);
+        if (e != hipSuccess)
+            return fail_hip(e, "sum kernel launch");
+    }
     return PTGPU_OK;
+}
+
+} // namespace
+
+int ptgpu_render_device(const ptgpu_scene *s, uint8_t *d_frame, size_t framew,
+                        size_t frameh, const ptgpu_params *p,
+                        void *hip_stream) {
+    if (d_frame == nullptr)
+        return fail(PTGPU_ERR_INVALID, "d_frame is NULL");
+    return render_common(s, d_frame, nullptr, framew, frameh, p,
+                         (hipStream_t)hip_stream);
 }
 
 int ptgpu_accumulate_device(const ptgpu_scene *s, float *d_accum,
@@ -435,20 +647,8 @@ int ptgpu_accumulate_device(const ptgpu_scene *s, float *d_accum,
         return fail(PTGPU_ERR_INVALID, "d_accum is NULL");
     if ((reinterpret_cast<uintptr_t>(d_accum) & 15u) != 0)
         return fail(PTGPU_ERR_INVALID, "d_accum must be 16-byte aligned");
-    pt::LaunchArgs a;
-    uint32_t block = 0;
-    bool tree = false;
-    int rc = prepare_launch(s, framew, frameh, p, &a, &block, &tree);
-    if (rc != PTGPU_OK)
-        return rc;
-    a.frame = nullptr;
-    a.accum = d_accum;
-    hipError_t e =
-        pt::launch_megakernel(a, block, tree, (hipStream_t)hip_stream);
-    if (e != hipSuccess)
-        return fail_hip(e, "megakernel launch (accumulate)");
-    count_launch();
-    return PTGPU_OK;
+    return render_common(s, nullptr, d_accum, framew, frameh, p,
+                         (hipStream_t)hip_stream);
 }
 
 int ptgpu_resolve_device(const float *d_accum, uint8_t *d_frame,
@@ -476,7 +676,7 @@ int render_frame_with(const ptgpu_scene *s, uint8_t *frame, size_t framew,
                       size_t frameh, const ptgpu_params *p) {
     ptgpu_params q = *p;
     q.flags |= PTGPU_FLAG_COMPACT_ROWS;
-    pt::LaunchArgs a;
+    pt::LaunchArgs a; // only for the row map and sizes
     uint32_t block = 0;
     bool tree = false;
     int rc = prepare_launch(s, framew, frameh, &q, &a, &block, &tree);
@@ -486,15 +686,14 @@ int render_frame_with(const ptgpu_scene *s, uint8_t *frame, size_t framew,
     const size_t bytes = row_bytes * a.num_rows;
     uint8_t *d_rows = nullptr;
     PT_TRY_HIP(hipMalloc(&d_rows, bytes));
-    a.frame = d_rows;
-    hipError_t e = pt::launch_megakernel(a, block, tree, nullptr);
-    count_launch();
-    if (e == hipSuccess)
+    rc = render_common(s, d_rows, nullptr, framew, frameh, &q, nullptr);
+    hipError_t e = hipSuccess;
+    if (rc == PTGPU_OK)
         e = hipDeviceSynchronize();
     // copy back run by run (a run = consecutive local rows that are also
     // consecutive global rows)
     uint32_t i = 0;
-    while (e == hipSuccess && i < a.num_rows) {
+    while (rc == PTGPU_OK && e == hipSuccess && i < a.num_rows) {
         uint32_t j = i + 1;
         while (j < a.num_rows && global_row(a, j) == global_row(a, j - 1) + 1)
             ++j;
@@ -504,6 +703,8 @@ int render_frame_with(const ptgpu_scene *s, uint8_t *frame, size_t framew,
         i = j;
     }
     (void)hipFree(d_rows);
+    if (rc != PTGPU_OK)
+        return rc;
     if (e != hipSuccess)
         return fail_hip(e, "render_frame");
     return PTGPU_OK;

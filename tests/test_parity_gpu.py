@@ -217,6 +217,70 @@ def test_screened_scan_with_many_triangles_and_nan_radius(gpu, oracle):
     assert np.array_equal(got, ref) and np.array_equal(plain, ref)
 
 
+# ---- pixel-owner vs sample-queue schedules -----------------------------------------------
+@pytest.mark.parametrize("mode", [0x80, 0x100, 0x140, 0x120], ids=["owner", "queue", "queue+lds",
+                                                                   "queue+screened"])
+@pytest.mark.parametrize("cfg,w,h,spp,b", [(1, 200, 120, 9, 4), (0, 131, 77, 6, 4),
+                                           (5, 64, 40, 3, 8), (2, 96, 54, 5, 8)])
+def test_both_schedules_give_the_oracle_frame(gpu, oracle, cfg, w, h, spp, b, mode):
+    with gpu.HostScene(cfg) as s:
+        got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=77, flags=mode)
+        ref, rays = oracle.render_rows(s, w, h, spp=spp, max_bounces=b, seed=77)
+    assert np.array_equal(got, ref)
+
+
+def test_sample_queue_in_several_passes_and_on_a_shard(gpu, torch_cuda, oracle, monkeypatch):
+    """A 64 MiB sample buffer forces several queue passes; the row set is an
+    interleaved shard written compactly; the caller's accumulator is used."""
+    from path_tracer_c_amd import tiles
+    torch = torch_cuda
+    monkeypatch.setenv("PTGPU_SCRATCH_MB", "64")
+    w, h, spp = 640, 360, 24                       # 230k pixels * 16 B = 3.7 MB per sample
+    kw = dict(max_bounces=4, seed=9)
+    stream = torch.cuda.current_stream().cuda_stream
+    with gpu.HostScene(1) as s, gpu.DeviceScene(s) as d:
+        gpu.host.reset_stats()
+        full_q = render_device(gpu, torch, d, w, h, spp=spp, flags=0x100, **kw)
+        st = gpu.host.read_stats()
+        assert st.launches >= 2                    # 24 spp did not fit one pass
+        full_o = render_device(gpu, torch, d, w, h, spp=spp, flags=0x80, **kw)
+        assert np.array_equal(full_q, full_o)
+        sh = tiles.shard_rows(h, 3, 1, 8)
+        part = render_device(gpu, torch, d, w, h, spp=spp, row_begin=sh.row_begin,
+                             num_rows=sh.num_rows, tile_rows=sh.tile_rows,
+                             tile_stride=sh.tile_stride, flags=0x101, **kw)
+        assert np.array_equal(part[: sh.num_rows], full_o[sh.global_rows()])
+        # caller's accumulator, two calls of 12 spp, queue then owner
+        acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        d.accumulate(acc.data_ptr(), w, h, gpu.make_params(spp=12, flags=0x100, **kw), stream)
+        d.accumulate(acc.data_ptr(), w, h, gpu.make_params(spp=12, sample_offset=12, flags=0x80, **kw), stream)
+        out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+        gpu.host.resolve(acc.data_ptr(), out.data_ptr(), w * h, stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), full_o)
+        ref, _ = oracle.render_rows(s, w, h, 100, 102, spp=spp, **kw)
+        assert np.array_equal(full_q[100:102], ref[100:102])
+
+
+def test_schedule_is_measured_once_per_scene_and_cached(gpu, torch_cuda):
+    """With neither schedule flag, the first large render of a scene measures
+    lane utilisation (1000 spheres under an open sky -> sample queue) and later
+    renders reuse the choice; all of them give the same frame."""
+    torch = torch_cuda
+    w, h, spp = 512, 512, 32
+    kw = dict(spp=spp, max_bounces=4, seed=4)
+    with gpu.HostScene(5) as s, gpu.DeviceScene(s) as d:
+        owner = render_device(gpu, torch, d, w, h, flags=0x80, **kw)
+        gpu.host.reset_stats()
+        first = render_device(gpu, torch, d, w, h, **kw)      # pilot + remainder
+        n_first = gpu.host.read_stats().launches
+        gpu.host.reset_stats()
+        second = render_device(gpu, torch, d, w, h, **kw)     # cached choice
+        n_second = gpu.host.read_stats().launches
+    assert np.array_equal(first, owner) and np.array_equal(second, owner)
+    assert n_first == n_second + 1                # the pilot launch happened once
+
+
 def test_same_seed_same_bytes_other_seed_other_bytes(gpu):
     with gpu.HostScene(2) as s:
         a = gpu.render_frame(s, 128, 72, spp=8, max_bounces=8, seed=1)

@@ -1,8 +1,9 @@
 import sys
 sys.path.insert(0, '.')
 from tools.sweep_settle import run
-for flags in (0x10, 0x20, 0x12, 0x22):
-    run('c5', spp=32, flags=flags, block=64 if flags & 2 else 256)
-    run('c5', spp=32, flags=flags, block=256 if flags & 2 else 512)
-for flags in (0x10, 0x20, 0x12, 0x22):
-    run('c2', flags=flags, block=64 if flags & 2 else 256)
+for name, kw in (('c5', dict(spp=64)), ('c2', {}), ('c1', dict(w=1920, h=1080, spp=256)), ('c0', dict())):
+    ref = None
+    for flags in (0x80, 0x100, 0):
+        img = run(name, flags=flags, **kw)
+        if ref is None: ref = img
+        assert (img == ref).all()
