@@ -303,6 +303,7 @@ def main():
                 "rays_per_sample": rays / samples if samples else None,
                 "msample_per_s": samples / elapsed / 1e6,
                 "lane_utilisation": rays / (64.0 * wave_iters) if wave_iters else None,
+                "schedule": dscene.schedule,
             },
             "roofline": {
                 "kernel": "pt_megakernel",

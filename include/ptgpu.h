@@ -143,6 +143,9 @@ int ptgpu_scene_upload(const scene *host_scene, ptgpu_scene **out);
 void ptgpu_scene_free(ptgpu_scene *s);
 /* 1 if some material has 0 < transparency < 1 (needs the tree kernel). */
 int ptgpu_scene_is_branching(const ptgpu_scene *s);
+/* Schedule remembered for this scene: 0 not measured yet, 1 pixel-owner,
+ * 2 sample-queue (see PTGPU_FLAG_PIXEL_OWNER / _SAMPLE_QUEUE). */
+int ptgpu_scene_schedule(const ptgpu_scene *s);
 
 /* -- rendering ------------------------------------------------------------- */
 /* Asynchronous: renders the row set of `p` of a framew x frameh image into
@@ -179,6 +182,9 @@ int ptgpu_trace_rays(const scene *host_scene, const float *origins,
 /* -- bookkeeping ------------------------------------------------------------ */
 int ptgpu_stats_reset(void);
 int ptgpu_stats_read(ptgpu_stats *out); /* synchronises the device */
+/* Frees the per-device sample/accumulator scratch of the sample-queue
+ * schedule (up to PTGPU_SCRATCH_MB, default 2048 MiB; regrown on demand). */
+int ptgpu_release_scratch(void);
 const char *ptgpu_last_error(void);     /* thread-local, never NULL */
 const char *ptgpu_version(void);
 

@@ -287,6 +287,12 @@ void ptgpu_scene_free(ptgpu_scene *s) {
     delete s;
 }
 
+int ptgpu_scene_schedule(const ptgpu_scene *s) {
+    if (s == nullptr)
+        return fail(PTGPU_ERR_INVALID, "scene is NULL");
+    return s->queue_mode.load() + 1; // 0 not measured, 1 pixel-owner, 2 sample-queue
+}
+
 int ptgpu_scene_is_branching(const ptgpu_scene *s) {
     if (s == nullptr)
         return fail(PTGPU_ERR_INVALID, "scene is NULL");
@@ -422,6 +428,8 @@ struct DeviceScratch {
     uint32_t *chunk_counters = nullptr; // ring of kCounterRing counters
     uint32_t next_counter = 0;
     uint32_t max_waves = 0;     // waves the device keeps resident
+    hipEvent_t last_use = nullptr; // end of the last frame that used the scratch
+    std::mutex lock;            // held while a frame's launches are enqueued
 };
 constexpr uint32_t kCounterRing = 256;
 DeviceScratch g_scratch[kMaxDevices];
@@ -455,6 +463,7 @@ int scratch_for_current_device(DeviceScratch **out) {
     DeviceScratch &sc = g_scratch[dev];
     if (sc.chunk_counters == nullptr) {
         PT_TRY_HIP(hipMalloc(&sc.chunk_counters, kCounterRing * sizeof(uint32_t)));
+        PT_TRY_HIP(hipEventCreateWithFlags(&sc.last_use, hipEventDisableTiming));
         hipDeviceProp_t prop;
         PT_TRY_HIP(hipGetDeviceProperties(&prop, dev));
         const int per_cu = prop.maxThreadsPerMultiProcessor / 64;
@@ -510,6 +519,16 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
     rc = scratch_for_current_device(&sc);
     if (rc != PTGPU_OK)
         return rc;
+    // The scratch buffers are shared by every frame on this device: enqueue
+    // one frame at a time, and make this stream wait for the previous frame
+    // that used them (which may have run on another stream).
+    std::lock_guard<std::mutex> scratch_guard(sc->lock);
+    PT_TRY_HIP(hipStreamWaitEvent(stream, sc->last_use, 0));
+    struct MarkUse {
+        DeviceScratch *sc;
+        hipStream_t stream;
+        ~MarkUse() { (void)hipEventRecord(sc->last_use, stream); }
+    } mark_use{sc, stream};
     float *accum = d_accum;
     a.accum_local = 0;
     bool accum_is_zero = false; // scratch accumulator not written yet
@@ -795,6 +814,24 @@ int ptgpu_stats_read(ptgpu_stats *out) {
     out->wave_iters = host.wave_iters;
     int dev = 0;
     out->launches = (current_device(&dev) == PTGPU_OK) ? g_launches[dev].load() : 0;
+    return PTGPU_OK;
+}
+
+int ptgpu_release_scratch(void) {
+    int dev = 0;
+    int rc = current_device(&dev);
+    if (rc != PTGPU_OK)
+        return rc;
+    DeviceScratch &sc = g_scratch[dev];
+    std::lock_guard<std::mutex> guard(sc.lock);
+    PT_TRY_HIP(hipDeviceSynchronize());
+    if (sc.samples)
+        (void)hipFree(sc.samples);
+    if (sc.accum)
+        (void)hipFree(sc.accum);
+    sc.samples = nullptr;
+    sc.accum = nullptr;
+    sc.sample_bytes = sc.accum_bytes = 0;
     return PTGPU_OK;
 }
 

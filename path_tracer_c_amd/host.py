@@ -178,6 +178,12 @@ class DeviceScene:
     def branching(self) -> bool:
         return bool(check(lib().ptgpu_scene_is_branching(self.handle)))
 
+    @property
+    def schedule(self) -> str:
+        """Schedule the library remembered for this scene."""
+        return ("unmeasured", "pixel-owner", "sample-queue")[
+            check(lib().ptgpu_scene_schedule(self.handle))]
+
     def render(self, d_frame_ptr: int, width: int, height: int, params: Params,
                stream: int = 0):
         check(lib().ptgpu_render_device(self.handle, C.c_void_p(d_frame_ptr),

@@ -277,8 +277,52 @@ def test_schedule_is_measured_once_per_scene_and_cached(gpu, torch_cuda):
         gpu.host.reset_stats()
         second = render_device(gpu, torch, d, w, h, **kw)     # cached choice
         n_second = gpu.host.read_stats().launches
+        schedule = d.schedule
     assert np.array_equal(first, owner) and np.array_equal(second, owner)
     assert n_first == n_second + 1                # the pilot launch happened once
+    assert schedule == "sample-queue"
+
+
+def test_queue_frames_on_two_streams_share_the_scratch_safely(gpu, torch_cuda):
+    """Two frames enqueued back to back on different streams use the same
+    per-device sample buffer; the second must wait for the first."""
+    torch = torch_cuda
+    w, h = 320, 200
+    with gpu.HostScene(1) as s1, gpu.HostScene(0) as s0, \
+            gpu.DeviceScene(s1) as d1, gpu.DeviceScene(s0) as d0:
+        ref1 = render_device(gpu, torch, d1, w, h, spp=12, seed=3, flags=0x80)
+        ref0 = render_device(gpu, torch, d0, w, h, spp=12, seed=3, flags=0x80)
+        a = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+        b = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            d1.render(a.data_ptr(), w, h, gpu.make_params(spp=12, seed=3, flags=0x100), sa.cuda_stream)
+            d0.render(b.data_ptr(), w, h, gpu.make_params(spp=12, seed=3, flags=0x100), sb.cuda_stream)
+        torch.cuda.synchronize()
+    assert np.array_equal(a.cpu().numpy(), ref1) and np.array_equal(b.cpu().numpy(), ref0)
+    assert gpu.lib().ptgpu_release_scratch() == 0
+
+
+def test_host_driver_binary_writes_the_same_picture(gpu, tmp_path, monkeypatch):
+    """bin/ptrender is a plain-C program against the legacy headers only
+    (scene_*, threadpool_*, render_task, write_bitmap)."""
+    import subprocess
+    from pathlib import Path
+    exe = Path(__file__).resolve().parent.parent / "bin" / "ptrender"
+    assert exe.exists(), "run make"
+    out = tmp_path / "out.bmp"
+    env = dict(os.environ, PTGPU_SPP="6", PTGPU_BOUNCES="4", PTGPU_SEED="5")
+    res = subprocess.run([str(exe), "0", "72", "40", str(out)], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    assert "Mray/s" in res.stdout
+    data = out.read_bytes()
+    assert data[:2] == b"BM" and len(data) == 54 + 72 * 40 * 3
+    pix = np.frombuffer(data[54:], dtype=np.uint8).reshape(40, 72, 3)[::-1, :, ::-1]  # bottom-up BGR
+    with gpu.HostScene(0) as s:
+        ref = gpu.render_frame(s, 72, 40, spp=6, max_bounces=4, seed=5)
+    assert np.array_equal(pix, ref)
 
 
 def test_same_seed_same_bytes_other_seed_other_bytes(gpu):
