@@ -270,7 +270,9 @@ def main():
 
     if rank == 0:
         rays_per_step = rays / args.steps
-        launches_per_step = n_pass
+        # megakernel launches per frame: 1 in pixel-owner mode, one per queue
+        # pass in sample-queue mode, one per progressive pass for c3
+        launches_per_step = max(1, round(st.launches / args.steps))
         fpr = flop_per_ray(n_sph, n_tri)
         # per-GPU kernel: this rank's share of the rays over its kernel time
         rays_per_launch = rays_per_step / world / launches_per_step
@@ -306,7 +308,7 @@ def main():
                 "schedule": dscene.schedule,
             },
             "roofline": {
-                "kernel": "pt_megakernel",
+                "kernel": "pt_samplekernel" if dscene.schedule == "sample-queue" else "pt_megakernel",
                 "bound": "valu",
                 "achieved": achieved_tflops,
                 "peak": PEAK_FP32_VECTOR_TFLOPS,
