@@ -392,15 +392,17 @@ stage_scene(const LaunchArgs &a, uint4 *lds_dyn, uint32_t tid, uint32_t nthreads
         const F4 *base = reinterpret_cast<const F4 *>(lds_dyn);
         w.rec.geom = base;
         w.rec.tri = base + n_obj;
-        w.rec.mat = base + n_obj + 3u * n_tri;
-        w.rec.meta = reinterpret_cast<const uint32_t *>(base + n_obj + 3u * n_tri +
+        w.rec.mat = base + n_obj + 4u * n_tri;
+        w.rec.meta = reinterpret_cast<const uint32_t *>(base + n_obj + 4u * n_tri +
                                                         2u * n_mat);
+        w.rec.link = w.rec.meta + n_obj;
         lds_used16 = blob16;
     } else {
         w.rec.geom = a.scene.geom;
         w.rec.tri = a.scene.tri;
         w.rec.mat = a.scene.mat;
         w.rec.meta = a.scene.meta;
+        w.rec.link = a.scene.link;
     }
     w.stack = reinterpret_cast<uint16_t *>(lds_dyn + lds_used16) + tid;
     // the candidate queues of the screened scan sit behind the bounce stack
@@ -566,6 +568,7 @@ __global__ void __launch_bounds__(1024)
                     const F4 *__restrict__ scene_tri,
                     const F4 *__restrict__ scene_mat,
                     const uint32_t *__restrict__ scene_meta,
+                    const uint32_t *__restrict__ scene_link,
                     float4 *__restrict__ out,
                     uint32_t *__restrict__ chunk_counter) {
     extern __shared__ uint4 lds_dyn[];
@@ -578,6 +581,7 @@ __global__ void __launch_bounds__(1024)
         w.rec.tri = scene_tri;
         w.rec.mat = scene_mat;
         w.rec.meta = scene_meta;
+        w.rec.link = scene_link;
     }
     const V3 sky = V3{a.scene.sky[0], a.scene.sky[1], a.scene.sky[2]};
     const uint32_t npix = a.num_rows * a.framew;
@@ -758,6 +762,7 @@ __global__ void __launch_bounds__(256)
     rec.tri = scene.tri;
     rec.mat = scene.mat;
     rec.meta = scene.meta;
+    rec.link = scene.link;
     rec.n_obj = scene.n_obj;
     const V3 o = V3{origins[3 * at], origins[3 * at + 1], origins[3 * at + 2]};
     const V3 d = V3{directions[3 * at], directions[3 * at + 1],
@@ -848,7 +853,8 @@ static hipError_t launch_sample_variant(const LaunchArgs &a, uint32_t grid,
     }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds_bytes, stream, a,
                        a.scene.geom, a.scene.tri, a.scene.mat, a.scene.meta,
-                       reinterpret_cast<float4 *>(a.sample_buf), a.chunk_counter);
+                       a.scene.link, reinterpret_cast<float4 *>(a.sample_buf),
+                       a.chunk_counter);
     return hipGetLastError();
 }
 

@@ -6,11 +6,14 @@
 // (include/shapes.h:29-36, src/ray.c:12-13) and fetches a 44-byte material per
 // hit (src/renderer.c:34).  Device layout instead, all 16-byte records:
 //
-//   geom[i]  float4   sphere  : centre.xyz, radius*radius
-//                     triangle: v0.xyz, bits(0x80000000 | triangle ordinal k)
-//   meta[i]  uint32   bit 31 = triangle, bits 0..30 = material index
-//   tri[3k..3k+2]     float4  edge1 = v1-v0 | edge2 = v2-v0 | unit normal
+//   geom[i]  float4   sphere  : centre.xyz, radius*radius        (w >= 0)
+//                     triangle: centre and -(radius^2) of a bounding sphere,
+//                               slightly inflated; the sign bit of w is the
+//                               record tag (spheres have it clear, also r = 0)
+//   tri[4k..4k+3]     float4  v0 | edge1 = v1-v0 | edge2 = v2-v0 | unit normal
 //                     crossn(v0-v1, v0-v2) (src/ray.c:50-52), w unused
+//   meta[i]  uint32   material index
+//   link[i]  uint32   triangle ordinal k (0 for spheres)
 //   mat[2m], mat[2m+1] float4 albedo.rgb, roughness*0.5 |
 //                     emission_color*emission_strength, transparency
 //
@@ -42,9 +45,10 @@ struct F4 { // plain 16-byte record usable on host and device
 // One device-resident scene: a single allocation, records at these offsets.
 struct SceneDesc {
     const F4 *geom;       // n_obj
-    const F4 *tri;        // 3 * n_tri
+    const F4 *tri;        // 4 * n_tri
     const F4 *mat;        // 2 * n_mat
     const uint32_t *meta; // n_obj
+    const uint32_t *link; // n_obj
     uint32_t n_obj;
     uint32_t n_tri;
     uint32_t n_mat;
@@ -53,10 +57,11 @@ struct SceneDesc {
     uint32_t pad;
 };
 
-// LDS bytes the scene copy needs (16-byte records first, then meta).
+// Bytes of the scene blob = LDS bytes its copy needs (16-byte records first,
+// then meta, then link).
 PT_LAYOUT_HD size_t scene_lds_bytes(uint32_t n_obj, uint32_t n_tri, uint32_t n_mat) {
-    size_t b = (size_t)16 * ((size_t)n_obj + 3u * (size_t)n_tri + 2u * (size_t)n_mat);
-    b += (size_t)4 * n_obj;
+    size_t b = (size_t)16 * ((size_t)n_obj + 4u * (size_t)n_tri + 2u * (size_t)n_mat);
+    b += (size_t)8 * n_obj; // meta + link
     return (b + 15u) & ~(size_t)15u;
 }
 

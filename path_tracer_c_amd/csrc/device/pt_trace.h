@@ -25,19 +25,17 @@ struct SceneRecords {
     const F4 *tri;
     const F4 *mat;
     const uint32_t *meta;
+    const uint32_t *link;
     uint32_t n_obj;
 };
 
 PT_HD V3 xyz(const F4 &r) { return V3{r.x, r.y, r.z}; }
 
-// geom[i].w is r*r (sign bit clear) for a sphere and, for a triangle, the
-// bit pattern 0x80000000 | ordinal: the sign bit tells the two apart without
-// a second load.
+// geom[i].w is r*r (sign bit clear) for a sphere and -(bounding radius)^2 for
+// a triangle: the sign bit tells the two apart without a second load, and
+// |w| is a squared radius the screen can use for either.
 PT_HD bool is_triangle_record(const F4 &g) {
     return (__builtin_bit_cast(uint32_t, g.w) & 0x80000000u) != 0u;
-}
-PT_HD uint32_t triangle_ordinal(const F4 &g) {
-    return __builtin_bit_cast(uint32_t, g.w) & 0x7FFFFFFFu;
 }
 
 // glms_ray_sphere for a unit direction; `r2` is radius*radius.
@@ -101,10 +99,11 @@ PT_HD void test_object(const SceneRecords &rec, V3 o, V3 d, uint32_t i,
         found = ray_sphere(o, d, xyz(g), g.w, t1, t2);
         dist = (t1 > 0.0f) ? t1 : t2; // src/ray.c:24
     } else {
-        const uint32_t k = triangle_ordinal(g);
-        const F4 e1 = rec.tri[3 * k + 0];
-        const F4 e2 = rec.tri[3 * k + 1];
-        found = ray_triangle(o, d, xyz(g), xyz(e1), xyz(e2), dist);
+        const uint32_t k = rec.link[i];
+        const F4 v0 = rec.tri[4 * k + 0];
+        const F4 e1 = rec.tri[4 * k + 1];
+        const F4 e2 = rec.tri[4 * k + 2];
+        found = ray_triangle(o, d, xyz(v0), xyz(e1), xyz(e2), dist);
     }
     if (found && !(dist >= h.distance && h.distance > 0.0f)) {
         h.distance = dist;
@@ -132,7 +131,9 @@ PT_HD Hit closest_hit(const SceneRecords &rec, V3 o, V3 d) {
 //            with err = 2^-16 * (|c-o|^2 + r^2) (>= 250x the rounding error of
 //            either formulation, direction normalisation error included) a
 //            sphere is dropped only if |dp_perp|^2 - r^2 > err.  NaN/overflow
-//            compare false -> kept.  Triangle records are always kept.
+//            compare false -> kept.  A triangle is screened through its
+//            bounding sphere (radius inflated by 1e-3 at upload, far more
+//            than Moeller-Trumbore's own edge tolerance).
 //   resolve  each lane appends the indices of its surviving objects, in
 //            ascending order, to its own queue in LDS (kScreenQueue entries);
 //            when some lane's queue could overflow during the next block of
@@ -149,16 +150,17 @@ struct ScreenQueue {
 };
 
 __device__ __forceinline__ bool screen_keep(const F4 g, V3 o, V3 d) {
-    // computed for every record (for a triangle record the numbers mean
-    // nothing and the result is overridden): no branch between the record
-    // fetch and the arithmetic, so the eight fetches of a block stay batched
+    // |w| is r^2 of the sphere itself, or of a triangle's bounding sphere:
+    // one branch-free test for every record, so the eight fetches of a block
+    // stay batched
+    const float r2 = __builtin_fabsf(g.w);
     const float dx = g.x - o.x, dy = g.y - o.y, dz = g.z - o.z;
     const float ddp = __builtin_fmaf(dz, d.z, __builtin_fmaf(dy, d.y, dx * d.x));
     const float dpp = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
     const float perp2 = __builtin_fmaf(-ddp, ddp, dpp);
     // certainly misses iff (perp2 - r2) - 2^-16 * (dpp + r2) > 0
-    const float excess = __builtin_fmaf(dpp + g.w, -0x1.0p-16f, perp2 - g.w);
-    return (bool)((int)is_triangle_record(g) | (int)!(excess > 0.0f));
+    const float excess = __builtin_fmaf(dpp + r2, -0x1.0p-16f, perp2 - r2);
+    return !(excess > 0.0f);
 }
 
 __device__ __forceinline__ Hit closest_hit_screened(const SceneRecords &rec,
@@ -224,8 +226,8 @@ PT_HD Surface surface_at(const SceneRecords &rec, V3 o, V3 d, Hit h) {
     if (!is_triangle_record(g)) {
         s.normal = normalize(s.point - xyz(g));
     } else {
-        const uint32_t k = triangle_ordinal(g);
-        V3 n = xyz(rec.tri[3 * k + 2]);
+        const uint32_t k = rec.link[h.object];
+        V3 n = xyz(rec.tri[4 * k + 3]);
         if (dot(n, d) > 0.0f)
             n = -n;
         s.normal = n;

@@ -89,6 +89,63 @@ int counters_for_current_device(pt::Counters **out) {
 
 pt::V3 to_v3(const vec3s &v) { return pt::V3{v.x, v.y, v.z}; }
 
+// geom record of a triangle: its smallest enclosing sphere (midpoint of the
+// longest edge if the triangle is right or obtuse, else the circumcentre),
+// computed in double, the radius inflated by 1e-3 and r^2 rounded up, stored
+// as (centre, -r^2).  Only the conservative screen of the large-scene scan
+// uses it; a degenerate or non-finite triangle gets an infinite radius
+// (always kept), so screening can never drop what the exact test would hit.
+pt::F4 bounding_sphere_record(const triangle &t) {
+    const double p[3][3] = {{t.v0.x, t.v0.y, t.v0.z},
+                            {t.v1.x, t.v1.y, t.v1.z},
+                            {t.v2.x, t.v2.y, t.v2.z}};
+    auto dist2 = [](const double *a, const double *b) {
+        double s = 0;
+        for (int i = 0; i < 3; ++i)
+            s += (a[i] - b[i]) * (a[i] - b[i]);
+        return s;
+    };
+    double c[3] = {0, 0, 0};
+    // longest edge and the vertex opposite to it
+    int ia = 0, ib = 1, ic = 2;
+    double longest = dist2(p[0], p[1]);
+    if (dist2(p[1], p[2]) > longest) { longest = dist2(p[1], p[2]); ia = 1; ib = 2; ic = 0; }
+    if (dist2(p[2], p[0]) > longest) { longest = dist2(p[2], p[0]); ia = 2; ib = 0; ic = 1; }
+    for (int i = 0; i < 3; ++i)
+        c[i] = 0.5 * (p[ia][i] + p[ib][i]);
+    double r2 = 0.25 * longest;
+    if (dist2(c, p[ic]) > r2) { // acute: circumcentre
+        double ab[3], ac[3], n[3];
+        for (int i = 0; i < 3; ++i) { ab[i] = p[1][i] - p[0][i]; ac[i] = p[2][i] - p[0][i]; }
+        n[0] = ab[1] * ac[2] - ab[2] * ac[1];
+        n[1] = ab[2] * ac[0] - ab[0] * ac[2];
+        n[2] = ab[0] * ac[1] - ab[1] * ac[0];
+        const double n2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+        const double ab2 = ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2];
+        const double ac2 = ac[0] * ac[0] + ac[1] * ac[1] + ac[2] * ac[2];
+        // centre - p0 = (|ac|^2 (n x ab) ... ) standard form:
+        // ((ab2 * ac) - (ac2 * ab)) x n / (2 n2), with sign arranged below
+        double u[3] = {ab2 * ac[0] - ac2 * ab[0], ab2 * ac[1] - ac2 * ab[1],
+                       ab2 * ac[2] - ac2 * ab[2]};
+        double w[3] = {u[1] * n[2] - u[2] * n[1], u[2] * n[0] - u[0] * n[2],
+                       u[0] * n[1] - u[1] * n[0]};
+        for (int i = 0; i < 3; ++i)
+            c[i] = p[0][i] + w[i] / (2.0 * n2);
+        r2 = std::max(dist2(c, p[0]), std::max(dist2(c, p[1]), dist2(c, p[2])));
+    }
+    // the stored centre is rounded to float: measure the radius from it
+    const float cf[3] = {(float)c[0], (float)c[1], (float)c[2]};
+    const double cd[3] = {cf[0], cf[1], cf[2]};
+    r2 = std::max(dist2(cd, p[0]), std::max(dist2(cd, p[1]), dist2(cd, p[2])));
+    double r = std::sqrt(r2) * 1.001 + 1e-30;
+    float r2f = (float)(r * r);
+    r2f = std::nextafter(r2f, std::numeric_limits<float>::infinity());
+    if (!(r2f == r2f) || !std::isfinite(cf[0]) || !std::isfinite(cf[1]) ||
+        !std::isfinite(cf[2]))
+        return pt::F4{0.0f, 0.0f, 0.0f, -std::numeric_limits<float>::infinity()};
+    return pt::F4{cf[0], cf[1], cf[2], -r2f};
+}
+
 } // namespace
 
 // The opaque handle of include/ptgpu.h.
@@ -201,8 +258,9 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
     std::vector<unsigned char> blob(bytes ? bytes : 16, 0);
     pt::F4 *geom = reinterpret_cast<pt::F4 *>(blob.data());
     pt::F4 *tri = geom + n_obj;
-    pt::F4 *mat = tri + 3u * (size_t)n_tri;
+    pt::F4 *mat = tri + 4u * (size_t)n_tri;
     uint32_t *meta = reinterpret_cast<uint32_t *>(mat + 2u * (size_t)n_mat);
+    uint32_t *link = meta + n_obj;
 
     uint32_t k = 0;
     for (uint32_t i = 0; i < n_obj; ++i) {
@@ -215,20 +273,20 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
             geom[i] = pt::F4{o.sphere.center.x, o.sphere.center.y,
                              o.sphere.center.z, r2};
             meta[i] = (uint32_t)o.material;
+            link[i] = 0;
         } else { // TRIANGLE
             const pt::V3 v0 = to_v3(o.triangle.v0), v1 = to_v3(o.triangle.v1),
                          v2 = to_v3(o.triangle.v2);
             const pt::V3 e1 = v1 - v0, e2 = v2 - v0;
             // glms_vec3_crossn(v0 - v1, v0 - v2), src/ray.c:50-52
             const pt::V3 n = pt::normalize(pt::cross(v0 - v1, v0 - v2));
-            float kbits;
-            const uint32_t tagged = k | 0x80000000u; // sign bit = triangle
-            std::memcpy(&kbits, &tagged, sizeof kbits);
-            geom[i] = pt::F4{v0.x, v0.y, v0.z, kbits};
-            tri[3 * k + 0] = pt::F4{e1.x, e1.y, e1.z, 0.0f};
-            tri[3 * k + 1] = pt::F4{e2.x, e2.y, e2.z, 0.0f};
-            tri[3 * k + 2] = pt::F4{n.x, n.y, n.z, 0.0f};
-            meta[i] = (uint32_t)o.material | pt::kMetaTriangle;
+            geom[i] = bounding_sphere_record(o.triangle);
+            tri[4 * k + 0] = pt::F4{v0.x, v0.y, v0.z, 0.0f};
+            tri[4 * k + 1] = pt::F4{e1.x, e1.y, e1.z, 0.0f};
+            tri[4 * k + 2] = pt::F4{e2.x, e2.y, e2.z, 0.0f};
+            tri[4 * k + 3] = pt::F4{n.x, n.y, n.z, 0.0f};
+            meta[i] = (uint32_t)o.material;
+            link[i] = k;
             ++k;
         }
     }
@@ -263,10 +321,11 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
     const pt::F4 *dbase = reinterpret_cast<const pt::F4 *>(h->blob);
     h->desc.geom = dbase;
     h->desc.tri = dbase + n_obj;
-    h->desc.mat = dbase + n_obj + 3u * (size_t)n_tri;
+    h->desc.mat = dbase + n_obj + 4u * (size_t)n_tri;
     h->desc.meta = reinterpret_cast<const uint32_t *>(dbase + n_obj +
-                                                      3u * (size_t)n_tri +
+                                                      4u * (size_t)n_tri +
                                                       2u * (size_t)n_mat);
+    h->desc.link = h->desc.meta + n_obj;
     h->desc.n_obj = n_obj;
     h->desc.n_tri = n_tri;
     h->desc.n_mat = n_mat;

@@ -325,6 +325,41 @@ def test_host_driver_binary_writes_the_same_picture(gpu, tmp_path, monkeypatch):
     assert np.array_equal(pix, ref)
 
 
+def test_triangle_mesh_is_screened_through_bounding_spheres(gpu, oracle):
+    """An 18x18 height-field (648 triangles, many of them slivers seen edge-on)
+    plus spheres: the screened scan may only drop triangles the exact
+    Moeller-Trumbore test would miss anyway."""
+    rng = np.random.default_rng(11)
+    n = 19
+    xs = np.linspace(-6, 6, n)
+    zs = np.linspace(2, 14, n)
+    hgt = rng.uniform(-1.6, -0.8, (n, n))
+    with gpu.HostScene() as s:
+        s.set_sky(0.5, 0.7, 0.9)
+        ground = s.add_material((0.5, 0.6, 0.3), roughness=0.9)
+        shiny = s.add_material((0.9, 0.9, 0.9), roughness=0.05)
+        glass = s.add_material((1, 1, 1), roughness=0.0, transparency=1.0)
+        for i in range(n - 1):
+            for k in range(n - 1):
+                a = (xs[i], hgt[i, k], zs[k]); b = (xs[i + 1], hgt[i + 1, k], zs[k])
+                c = (xs[i + 1], hgt[i + 1, k + 1], zs[k + 1]); e = (xs[i], hgt[i, k + 1], zs[k + 1])
+                s.add_triangle(a, b, c, ground if (i + k) % 5 else shiny)
+                s.add_triangle(a, e, c, ground)
+        s.add_triangle((0, 0, 6), (1e-4, 0, 6), (0, 3, 6.0001), shiny)      # sliver
+        s.add_triangle((1, 1, 5), (1, 1, 5), (2, 2, 5), ground)              # degenerate
+        for _ in range(12):
+            s.add_sphere(tuple(rng.uniform(-4, 4, 3) + np.array([0, 1.5, 8])), float(rng.uniform(0.3, 0.9)),
+                         [shiny, glass, ground][int(rng.integers(3))])
+        assert s.counts() == (12, 650)
+        got = gpu.render_frame(s, 112, 72, spp=4, max_bounces=5, seed=3)             # screened (default)
+        plain = gpu.render_frame(s, 112, 72, spp=4, max_bounces=5, seed=3, flags=0x10)
+        lds = gpu.render_frame(s, 112, 72, spp=4, max_bounces=5, seed=3, flags=0x140)  # lds + queue
+        ref, _ = oracle.render_rows(s, 112, 72, spp=4, max_bounces=5, seed=3)
+    assert np.array_equal(plain, ref)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(lds, ref)
+
+
 def test_same_seed_same_bytes_other_seed_other_bytes(gpu):
     with gpu.HostScene(2) as s:
         a = gpu.render_frame(s, 128, 72, spp=8, max_bounces=8, seed=1)
