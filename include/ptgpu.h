@@ -131,7 +131,8 @@ typedef struct ptgpu_scene ptgpu_scene;
 /* The reference's compile-time settings: 16 spp, 4 bounces, fov pi/2. */
 int ptgpu_params_default(ptgpu_params *p);
 /* Defaults overridden by PTGPU_SPP, PTGPU_BOUNCES, PTGPU_SEED, PTGPU_FOV_DEG,
- * PTGPU_BLOCK, PTGPU_FLAGS; this is what the legacy entry points use. */
+ * PTGPU_BLOCK, PTGPU_FLAGS, PTGPU_SETTLE; this is what the legacy entry points
+ * use (they also honour PTGPU_DEVICES, see ptgpu_render_frame_multi). */
 int ptgpu_params_from_env(ptgpu_params *p);
 
 /* -- devices --------------------------------------------------------------- */
@@ -173,6 +174,25 @@ int ptgpu_accumulate_device(const ptgpu_scene *s, float *d_accum,
  * (src/renderer.c:108-114). */
 int ptgpu_resolve_device(const float *d_accum, uint8_t *d_frame,
                          size_t npixels, void *hip_stream);
+
+/* Synchronous, single process, several GPUs: the frame's rows are dealt to
+ * `n_devices` devices as interleaved tiles of `tile_rows` rows (0 = 8), each
+ * device renders its tiles on its own stream, and the rows are copied
+ * straight into the caller's host frame -- the host buffer is the gather
+ * target, so no collective is needed.  `devices[i]` are HIP ordinals (an
+ * ordinal may repeat).  The frame does not depend on n_devices or tile_rows.
+ * The legacy entry points do the same when PTGPU_DEVICES=n is set. */
+int ptgpu_render_frame_multi(const scene *host_scene, uint8_t *frame,
+                             size_t framew, size_t frameh,
+                             const ptgpu_params *p, const int *devices,
+                             int n_devices, uint32_t tile_rows);
+
+/* -- device memory helpers for hosts without a HIP binding (C, cgo, ctypes) -- */
+int ptgpu_device_alloc(size_t bytes, void **out); /* hipMalloc, zero-filled */
+int ptgpu_device_free(void *ptr);
+int ptgpu_device_upload(void *dst_device, const void *src_host, size_t bytes);
+int ptgpu_device_download(void *dst_host, const void *src_device, size_t bytes);
+int ptgpu_device_synchronize(void);
 
 /* -- batched closest-hit queries (host buffers, synchronous) ---------------- */
 /* origins/directions: n x 3 floats; hits: n ray_hit records. */

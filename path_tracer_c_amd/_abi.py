@@ -197,6 +197,14 @@ SIGNATURES = {
                                       C.c_size_t, C.POINTER(Params), C.c_void_p]),
     "ptgpu_render_frame": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_size_t,
                                      C.c_size_t, C.POINTER(Params)]),
+    "ptgpu_render_frame_multi": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_size_t,
+                                           C.c_size_t, C.POINTER(Params),
+                                           C.POINTER(C.c_int), C.c_int, C.c_uint32]),
+    "ptgpu_device_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "ptgpu_device_free": (C.c_int, [C.c_void_p]),
+    "ptgpu_device_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ptgpu_device_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ptgpu_device_synchronize": (C.c_int, []),
     "ptgpu_accumulate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t,
                                           C.c_size_t, C.POINTER(Params),
                                           C.c_void_p]),

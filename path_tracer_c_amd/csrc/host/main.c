@@ -10,7 +10,16 @@
  *
  * usage: ptrender [config 0..5] [width] [height] [out.bmp]
  * Samples per pixel, bounce limit and seed come from PTGPU_SPP,
- * PTGPU_BOUNCES and PTGPU_SEED (defaults: the reference's 16 / 4).
+ * PTGPU_BOUNCES and PTGPU_SEED (defaults: the reference's 16 / 4);
+ * PTGPU_DEVICES=n spreads the rows over n GPUs.
+ *
+ * PTGPU_PROGRESSIVE=k switches to the explicit API (include/ptgpu.h): the
+ * frame is accumulated k samples at a time into a float accumulator in HBM
+ * and out.bmp is rewritten after every pass -- the windowless stand-in for
+ * the reference's real-time loop, which re-renders with a fresh seed each
+ * frame (src/main.c:250-286).  With PTGPU_RESUME=file the accumulator is
+ * loaded from / saved to that file, so an interrupted render continues at
+ * the sample it stopped at and ends with the very same image.
  */
 #include "ptgpu.h"
 
@@ -27,6 +36,78 @@ static double seconds_now(void) {
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
+static uint32_t env_number(const char *name, uint32_t fallback) {
+    const char *v = getenv(name);
+    return (v && *v) ? (uint32_t)strtoul(v, NULL, 0) : fallback;
+}
+
+static int progressive(scene *world, size_t width, size_t height, char *path,
+                       uint32_t per_pass) {
+    ptgpu_params p;
+    ptgpu_params_from_env(&p);
+    const uint32_t total = p.spp;
+    const size_t npix = width * height;
+    ptgpu_scene *dev = NULL;
+    void *d_accum = NULL, *d_frame = NULL;
+    uint8_t *frame = malloc(3 * npix);
+    float *accum = malloc(16 * npix);
+    int rc = ptgpu_scene_upload(world, &dev);
+    if (rc == PTGPU_OK) rc = ptgpu_device_alloc(16 * npix, &d_accum);
+    if (rc == PTGPU_OK) rc = ptgpu_device_alloc(3 * npix, &d_frame);
+    if (rc != PTGPU_OK || frame == NULL || accum == NULL) {
+        fprintf(stderr, "progressive setup failed: %s\n", ptgpu_last_error());
+        return 1;
+    }
+
+    /* resume: header {width, height, samples done} + the float4 accumulator */
+    uint32_t done = 0;
+    const char *resume = getenv("PTGPU_RESUME");
+    if (resume && *resume) {
+        FILE *in = fopen(resume, "rb");
+        uint64_t head[3];
+        if (in && fread(head, sizeof head, 1, in) == 1 && head[0] == width &&
+            head[1] == height && head[2] <= total &&
+            fread(accum, 16, npix, in) == npix) {
+            done = (uint32_t)head[2];
+            ptgpu_device_upload(d_accum, accum, 16 * npix);
+            printf("resumed %s at %u of %u spp\n", resume, done, total);
+        }
+        if (in) fclose(in);
+    }
+    uint32_t stop_after = env_number("PTGPU_STOP_AFTER", total); /* for tests */
+
+    double t0 = seconds_now();
+    while (done < total && done < stop_after) {
+        p.spp = total - done < per_pass ? total - done : per_pass;
+        p.sample_offset = done;
+        rc = ptgpu_accumulate_device(dev, d_accum, width, height, &p, NULL);
+        if (rc == PTGPU_OK) rc = ptgpu_resolve_device(d_accum, d_frame, npix, NULL);
+        if (rc == PTGPU_OK) rc = ptgpu_device_download(frame, d_frame, 3 * npix);
+        if (rc != PTGPU_OK) {
+            fprintf(stderr, "pass failed: %s\n", ptgpu_last_error());
+            return 1;
+        }
+        done += p.spp;
+        write_bitmap(path, (unsigned int)width, (unsigned int)height, frame, true);
+        printf("%u/%u spp  %.3f s\n", done, total, seconds_now() - t0);
+    }
+    if (resume && *resume && ptgpu_device_download(accum, d_accum, 16 * npix) == PTGPU_OK) {
+        FILE *out = fopen(resume, "wb");
+        uint64_t head[3] = {width, height, done};
+        if (out) {
+            fwrite(head, sizeof head, 1, out);
+            fwrite(accum, 16, npix, out);
+            fclose(out);
+        }
+    }
+    ptgpu_device_free(d_accum);
+    ptgpu_device_free(d_frame);
+    ptgpu_scene_free(dev);
+    free(frame);
+    free(accum);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     int config = argc > 1 ? atoi(argv[1]) : 0;
     size_t width = argc > 2 ? (size_t)atol(argv[2]) : WIDTH;
@@ -37,6 +118,13 @@ int main(int argc, char **argv) {
     if (ptgpu_build_config_scene(config, &world) != PTGPU_OK) {
         fprintf(stderr, "unknown scene configuration %d\n", config);
         return 1;
+    }
+
+    uint32_t per_pass = env_number("PTGPU_PROGRESSIVE", 0);
+    if (per_pass > 0) {
+        int status = progressive(&world, width, height, path, per_pass);
+        scene_destroy(&world);
+        return status;
     }
 
     uint8_t *frame = calloc(3 * width * height, 1);

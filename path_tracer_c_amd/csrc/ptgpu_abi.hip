@@ -809,6 +809,142 @@ int ptgpu_render_frame(const scene *host_scene, uint8_t *frame, size_t framew,
 }
 
 // ---------------------------------------------------------------------------
+// one process, several GPUs, host frame
+// ---------------------------------------------------------------------------
+int ptgpu_render_frame_multi(const scene *host_scene, uint8_t *frame,
+                             size_t framew, size_t frameh,
+                             const ptgpu_params *p, const int *devices,
+                             int n_devices, uint32_t tile_rows) {
+    if (frame == nullptr || devices == nullptr || n_devices <= 0 || n_devices > kMaxDevices)
+        return fail(PTGPU_ERR_INVALID, "bad frame or device list");
+    ptgpu_params defaults;
+    if (p == nullptr) {
+        ptgpu_params_default(&defaults);
+        p = &defaults;
+    }
+    if (p->tile_rows != 0 || (p->flags & PTGPU_FLAG_COMPACT_ROWS))
+        return fail(PTGPU_ERR_INVALID, "the multi-device call shards the rows itself");
+    if (framew == 0 || frameh == 0 || p->row_begin >= frameh)
+        return fail(PTGPU_ERR_INVALID, "frame size or row_begin out of range");
+    const uint32_t first = p->row_begin;
+    const uint32_t rows = p->num_rows ? p->num_rows : (uint32_t)frameh - first;
+    if ((uint64_t)first + rows > frameh)
+        return fail(PTGPU_ERR_INVALID, "row set reaches below the frame");
+    const uint32_t T = tile_rows ? tile_rows : 8u;
+    const uint32_t G = (uint32_t)n_devices;
+    const uint32_t n_tiles = (rows + T - 1) / T;
+    const size_t row_bytes = 3u * framew;
+
+    int home = 0;
+    PT_TRY_HIP(hipGetDevice(&home));
+    struct Shard {
+        ptgpu_scene *scene = nullptr;
+        uint8_t *rows = nullptr;
+        hipStream_t stream = nullptr;
+        uint32_t num_rows = 0;
+    };
+    std::vector<Shard> shard(G);
+    int rc = PTGPU_OK;
+    // enqueue every device's tiles first, then collect: the devices overlap
+    for (uint32_t r = 0; r < G && rc == PTGPU_OK; ++r) {
+        uint32_t mine = 0;
+        for (uint32_t t = r; t < n_tiles; t += G)
+            mine += (t + 1) * T <= rows ? T : rows - t * T;
+        shard[r].num_rows = mine;
+        if (mine == 0)
+            continue;
+        hipError_t e = hipSetDevice(devices[r]);
+        if (e == hipSuccess)
+            e = hipStreamCreateWithFlags(&shard[r].stream, hipStreamNonBlocking);
+        if (e == hipSuccess)
+            e = hipMalloc(&shard[r].rows, row_bytes * mine);
+        if (e != hipSuccess) {
+            rc = fail_hip(e, "multi-device setup");
+            break;
+        }
+        rc = ptgpu_scene_upload(host_scene, &shard[r].scene);
+        if (rc != PTGPU_OK)
+            break;
+        ptgpu_params q = *p;
+        q.row_begin = first + r * T;
+        q.num_rows = mine;
+        q.tile_rows = T;
+        q.tile_stride = G;
+        q.flags |= PTGPU_FLAG_COMPACT_ROWS;
+        rc = render_common(shard[r].scene, shard[r].rows, nullptr, framew, frameh,
+                           &q, shard[r].stream);
+    }
+    for (uint32_t r = 0; r < G; ++r) {
+        if (shard[r].num_rows == 0)
+            continue;
+        (void)hipSetDevice(devices[r]);
+        if (rc == PTGPU_OK && shard[r].stream) {
+            hipError_t e = hipStreamSynchronize(shard[r].stream);
+            uint32_t local = 0;
+            for (uint32_t t = r; t < n_tiles && e == hipSuccess; t += G) {
+                const uint32_t h = (t + 1) * T <= rows ? T : rows - t * T;
+                e = hipMemcpy(frame + row_bytes * (first + t * T),
+                              shard[r].rows + row_bytes * local, row_bytes * h,
+                              hipMemcpyDeviceToHost);
+                local += h;
+            }
+            if (e != hipSuccess)
+                rc = fail_hip(e, "multi-device collect");
+        }
+        ptgpu_scene_free(shard[r].scene);
+        if (shard[r].rows)
+            (void)hipFree(shard[r].rows);
+        if (shard[r].stream)
+            (void)hipStreamDestroy(shard[r].stream);
+    }
+    (void)hipSetDevice(home);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
+// device memory helpers
+// ---------------------------------------------------------------------------
+int ptgpu_device_alloc(size_t bytes, void **out) {
+    if (out == nullptr || bytes == 0)
+        return fail(PTGPU_ERR_INVALID, "bad allocation request");
+    *out = nullptr;
+    void *p = nullptr;
+    PT_TRY_HIP(hipMalloc(&p, bytes));
+    hipError_t e = hipMemset(p, 0, bytes);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return fail_hip(e, "hipMemset");
+    }
+    *out = p;
+    return PTGPU_OK;
+}
+
+int ptgpu_device_free(void *ptr) {
+    if (ptr != nullptr)
+        PT_TRY_HIP(hipFree(ptr));
+    return PTGPU_OK;
+}
+
+int ptgpu_device_upload(void *dst_device, const void *src_host, size_t bytes) {
+    if (dst_device == nullptr || src_host == nullptr)
+        return fail(PTGPU_ERR_INVALID, "NULL buffer");
+    PT_TRY_HIP(hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice));
+    return PTGPU_OK;
+}
+
+int ptgpu_device_download(void *dst_host, const void *src_device, size_t bytes) {
+    if (dst_host == nullptr || src_device == nullptr)
+        return fail(PTGPU_ERR_INVALID, "NULL buffer");
+    PT_TRY_HIP(hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost));
+    return PTGPU_OK;
+}
+
+int ptgpu_device_synchronize(void) {
+    PT_TRY_HIP(hipDeviceSynchronize());
+    return PTGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
 // batched closest-hit queries
 // ---------------------------------------------------------------------------
 int ptgpu_trace_rays(const scene *host_scene, const float *origins,
@@ -974,6 +1110,21 @@ void legacy_render_rows(const scene *world, uint8_t *frame, size_t framew,
     p.num_rows = num_rows;
     p.tile_rows = 0;
     p.tile_stride = 1;
+    uint32_t n_dev = 0;
+    if (env_u32("PTGPU_DEVICES", &n_dev) && n_dev > 1 && num_rows >= 2 * n_dev) {
+        int have = ptgpu_device_count();
+        if (have < 1)
+            die("device count");
+        if ((int)n_dev > kMaxDevices)
+            n_dev = kMaxDevices;
+        std::vector<int> devices(n_dev);
+        for (uint32_t i = 0; i < n_dev; ++i)
+            devices[i] = (int)(i % (uint32_t)have);
+        if (ptgpu_render_frame_multi(world, frame, framew, frameh, &p, devices.data(),
+                                     (int)n_dev, 0) != PTGPU_OK)
+            die("multi-device render");
+        return;
+    }
     ptgpu_scene *s = legacy_scene(world);
     if (render_frame_with(s, frame, framew, frameh, &p) != PTGPU_OK)
         die("render");

@@ -317,9 +317,7 @@ def test_host_driver_binary_writes_the_same_picture(gpu, tmp_path, monkeypatch):
                          text=True, timeout=120)
     assert res.returncode == 0, res.stderr
     assert "Mray/s" in res.stdout
-    data = out.read_bytes()
-    assert data[:2] == b"BM" and len(data) == 54 + 72 * 40 * 3
-    pix = np.frombuffer(data[54:], dtype=np.uint8).reshape(40, 72, 3)[::-1, :, ::-1]  # bottom-up BGR
+    pix = _bmp_pixels(out, 72, 40)
     with gpu.HostScene(0) as s:
         ref = gpu.render_frame(s, 72, 40, spp=6, max_bounces=4, seed=5)
     assert np.array_equal(pix, ref)
@@ -358,6 +356,65 @@ def test_triangle_mesh_is_screened_through_bounding_spheres(gpu, oracle):
     assert np.array_equal(plain, ref)
     assert np.array_equal(got, ref)
     assert np.array_equal(lds, ref)
+
+
+def _bmp_pixels(path, w, h):
+    data = Path(path).read_bytes()
+    assert data[:2] == b"BM" and len(data) == 54 + ((3 * w + 3) // 4 * 4) * h
+    stride = (3 * w + 3) // 4 * 4
+    rows = np.frombuffer(data[54:], dtype=np.uint8).reshape(h, stride)[:, : 3 * w]
+    return rows.reshape(h, w, 3)[::-1, :, ::-1]                        # bottom-up BGR -> top-down RGB
+
+
+def test_progressive_driver_resumes_to_the_same_picture(gpu, tmp_path):
+    """bin/ptrender in progressive mode: stop after 8 of 20 spp, resume from
+    the saved accumulator, and end with the image of an uninterrupted run."""
+    import subprocess
+    exe = Path(__file__).resolve().parent.parent / "bin" / "ptrender"
+    w, h = 70, 44
+    base = dict(os.environ, PTGPU_SPP="20", PTGPU_BOUNCES="4", PTGPU_SEED="9", PTGPU_PROGRESSIVE="4")
+    out = tmp_path / "p.bmp"
+    acc = tmp_path / "p.acc"
+    run = lambda env: subprocess.run([str(exe), "1", str(w), str(h), str(out)], env=env,
+                                     capture_output=True, text=True, timeout=120)
+    r1 = run(dict(base, PTGPU_RESUME=str(acc), PTGPU_STOP_AFTER="8"))
+    assert r1.returncode == 0 and "8/20 spp" in r1.stdout and "12/20" not in r1.stdout, r1.stdout + r1.stderr
+    r2 = run(dict(base, PTGPU_RESUME=str(acc)))
+    assert r2.returncode == 0 and "resumed" in r2.stdout and "20/20 spp" in r2.stdout, r2.stdout + r2.stderr
+    with gpu.HostScene(1) as s:
+        ref = gpu.render_frame(s, w, h, spp=20, max_bounces=4, seed=9)
+    assert np.array_equal(_bmp_pixels(out, w, h), ref)
+
+
+@pytest.mark.parametrize("n_dev,tile", [(2, 8), (3, 5), (4, 0)])
+def test_single_process_multi_device_frame(gpu, n_dev, tile):
+    """ptgpu_render_frame_multi deals interleaved row tiles to a device list
+    (here: the one GPU of the box, repeated) and copies rows straight into
+    the host frame; the frame equals the single-launch frame."""
+    w, h = 150, 83
+    p = gpu.make_params(spp=6, max_bounces=8, seed=2)
+    devices = (C.c_int * n_dev)(*([0] * n_dev))
+    with gpu.HostScene(2) as s:
+        ref = gpu.render_frame(s, w, h, spp=6, max_bounces=8, seed=2)
+        frame = np.zeros((h, w, 3), dtype=np.uint8)
+        gpu._abi.check(gpu.lib().ptgpu_render_frame_multi(
+            s.ptr(), frame.ctypes.data_as(C.c_void_p), w, h, C.byref(p), devices, n_dev, tile))
+        # a row subset through the same call
+        p2 = gpu.make_params(spp=6, max_bounces=8, seed=2, row_begin=10, num_rows=33)
+        part = np.zeros((h, w, 3), dtype=np.uint8)
+        gpu._abi.check(gpu.lib().ptgpu_render_frame_multi(
+            s.ptr(), part.ctypes.data_as(C.c_void_p), w, h, C.byref(p2), devices, n_dev, tile))
+    assert np.array_equal(frame, ref)
+    assert np.array_equal(part[10:43], ref[10:43]) and not part[:10].any() and not part[43:].any()
+
+
+def test_legacy_frame_over_several_devices(gpu, oracle, monkeypatch):
+    monkeypatch.setenv("PTGPU_SPP", "5")
+    monkeypatch.setenv("PTGPU_DEVICES", "3")
+    with gpu.HostScene(0) as s:
+        got = gpu.host.render_frame_legacy(s, 90, 61)
+        ref, _ = oracle.render_rows(s, 90, 61, spp=5, max_bounces=4, seed=1)
+    assert np.array_equal(got, ref)
 
 
 def test_same_seed_same_bytes_other_seed_other_bytes(gpu):
