@@ -198,11 +198,9 @@ def main():
     local = torch.zeros((pad_rows, w, 3), dtype=torch.uint8, device="cuda")
     accum = torch.zeros((pad_rows, w, 4), dtype=torch.float32, device="cuda") if progressive else None
     frame = local
+    gather_scratch = {}
     if world > 1:
-        parts = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
-        index = [torch.tensor(tiles.shard_rows(h, world, r, tile).global_rows(),
-                              dtype=torch.long, device="cuda") for r in range(world)] if rank == 0 else None
-        frame = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda") if rank == 0 else None
+        frame = None
 
     kernel_ms = []
 
@@ -222,18 +220,15 @@ def main():
             p = pt.make_params(spp=cfg["spp"], **base)
             dscene.render(local.data_ptr(), w, h, p, stream)
         ev1.record()
+        nonlocal frame
         if world > 1:
-            if args.backend == "nccl":
-                dist.gather(local, gather_list=parts, dst=0)
-            else:  # rehearsal: stage through host memory
-                host_parts = [torch.empty(local.shape, dtype=local.dtype) for _ in range(world)] if rank == 0 else None
-                dist.gather(local.cpu(), gather_list=host_parts, dst=0)
-                if rank == 0:
-                    for r in range(world):
-                        parts[r].copy_(host_parts[r])
+            if args.backend == "nccl":   # ONE gather over RCCL + one scatter kernel on rank 0
+                got = tiles.gather_frame(local, h, w, tile, scratch=gather_scratch)
+            else:                        # rehearsal: the same code path through host memory
+                got = tiles.gather_frame(local.cpu(), h, w, tile, scratch=gather_scratch)
+                got = got.cuda() if got is not None else None
             if rank == 0:
-                for r in range(world):
-                    frame.index_copy_(0, index[r], parts[r][: index[r].numel()])
+                frame = got
         if timed:
             kernel_ms.append((ev0, ev1))
 

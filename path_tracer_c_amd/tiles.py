@@ -62,14 +62,27 @@ def default_tile_rows(height: int, world: int) -> int:
     return t
 
 
+def scatter_index(height: int, world: int, tile_rows: int):
+    """For the stacked gather buffer of shape (world * pad, W, 3): the frame
+    row each buffer row belongs to; padding rows point at a spare row
+    `height` that the caller drops."""
+    pad = max_shard_rows(height, world, tile_rows)
+    index = []
+    for r in range(world):
+        rows = shard_rows(height, world, r, tile_rows).global_rows()
+        index += rows + [height] * (pad - len(rows))
+    return index
+
+
 def gather_frame(local_rows, height: int, width: int, tile_rows: int,
-                 group=None, dst: int = 0):
+                 group=None, dst: int = 0, scratch=None):
     """Gather the ranks' compact row buffers into the full frame on `dst`.
 
     `local_rows` is a uint8 tensor of shape (padded_rows, width, 3) where
     padded_rows = max_shard_rows(...) on every rank (equal message sizes for
     the one gather); only the first shard.num_rows rows are meaningful.
-    Returns the (height, width, 3) frame on `dst`, None elsewhere.
+    Returns the (height, width, 3) frame on `dst`, None elsewhere.  `scratch`
+    (dst only) may carry {"stack", "index", "frame"} tensors between calls.
     """
     import torch
     import torch.distributed as dist
@@ -78,17 +91,20 @@ def gather_frame(local_rows, height: int, width: int, tile_rows: int,
     rank = dist.get_rank(group)
     pad = max_shard_rows(height, world, tile_rows)
     assert local_rows.shape == (pad, width, 3), (local_rows.shape, pad)
-    parts = None
-    if rank == dst:
-        parts = [torch.empty_like(local_rows) for _ in range(world)]
-    dist.gather(local_rows, gather_list=parts, dst=dst, group=group)
     if rank != dst:
+        dist.gather(local_rows, gather_list=None, dst=dst, group=group)
         return None
-    frame = torch.empty((height, width, 3), dtype=local_rows.dtype,
-                        device=local_rows.device)
-    for r in range(world):
-        shard = shard_rows(height, world, r, tile_rows)
-        idx = torch.tensor(shard.global_rows(), dtype=torch.long,
-                           device=local_rows.device)
-        frame.index_copy_(0, idx, parts[r][: shard.num_rows])
-    return frame
+    if scratch is None:
+        scratch = {}
+    if "stack" not in scratch:
+        scratch["stack"] = torch.empty((world, pad, width, 3), dtype=local_rows.dtype,
+                                       device=local_rows.device)
+        scratch["index"] = torch.tensor(scatter_index(height, world, tile_rows),
+                                        dtype=torch.long, device=local_rows.device)
+        scratch["frame"] = torch.empty((height + 1, width, 3), dtype=local_rows.dtype,
+                                       device=local_rows.device)
+    stack = scratch["stack"]
+    dist.gather(local_rows, gather_list=[stack[r] for r in range(world)], dst=dst, group=group)
+    # one scatter un-interleaves all ranks' tiles (padding rows land in the spare row)
+    scratch["frame"].index_copy_(0, scratch["index"], stack.view(world * pad, width, 3))
+    return scratch["frame"][:height]
