@@ -191,7 +191,12 @@ def main():
     tile = args.tile_rows or tiles.default_tile_rows(h, world)
     shard = tiles.shard_rows(h, world, rank, tile)
     pad_rows = tiles.max_shard_rows(h, world, tile)
-    flags = args.flags | (pt._abi.FLAG_COMPACT_ROWS if world > 1 else 0)
+    # The timed headline scans the scene for EVERY counted ray: the library's
+    # default shares the (identical) primary-ray scan between the samples of a
+    # pixel, which lowers frame time but would count rays whose scan was not
+    # executed.  That mode is measured separately below (N = 1) and reported
+    # under config.primary_share, never as `value`.
+    flags = args.flags | pt._abi.FLAG_NO_PRIMARY_SHARE | (pt._abi.FLAG_COMPACT_ROWS if world > 1 else 0)
     base = dict(max_bounces=cfg["max_bounces"], seed=cfg["seed"], row_begin=shard.row_begin,
                 num_rows=shard.num_rows, tile_rows=shard.tile_rows if world > 1 else 0,
                 tile_stride=shard.tile_stride, flags=flags, block_threads=args.block)
@@ -321,6 +326,26 @@ def main():
                         "unit": "GB/s", "frac": hbm_alg / k_s / 1e9 / PEAK_HBM_GBS},
             },
         }
+        assert st.scans == st.rays, "headline must scan the scene for every counted ray"
+        if world == 1 and not progressive:
+            # library default: primary-ray scan shared between a pixel's samples
+            shared = pt.make_params(spp=cfg["spp"], **{**base, "flags": base["flags"] & ~pt._abi.FLAG_NO_PRIMARY_SHARE})
+            dscene.render(local.data_ptr(), w, h, shared, stream)
+            torch.cuda.synchronize()
+            pt.host.reset_stats()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                dscene.render(local.data_ptr(), w, h, shared, stream)
+            e1.record()
+            torch.cuda.synchronize()
+            s2 = pt.host.read_stats()
+            ms = e0.elapsed_time(e1) / 3
+            line["config"]["primary_share"] = {
+                "ms_per_step": ms, "path_segments_per_s_M": s2.rays / 3 / ms / 1e3,
+                "scene_scans_per_s_M": s2.scans / 3 / ms / 1e3,
+                "scans_per_segment": s2.scans / s2.rays,
+                "note": "library default; same image; not used for `value`"}
         if world == 1 and not args.no_cpu_baseline:
             host_frame = frame.cpu().numpy()
             base_line, rmse = cpu_baseline(pt, scene, cfg, lambda rows: host_frame[rows])

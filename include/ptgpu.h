@@ -84,6 +84,11 @@ extern "C" {
                                          stream once) and remembers the
                                          choice in the ptgpu_scene. */
 
+#define PTGPU_FLAG_NO_PRIMARY_SHARE 0x200u /* scheduling only: scan the scene
+                                         for the primary ray of every sample,
+                                         as the reference does, instead of once
+                                         per pixel (the ray is the same) */
+
 /* limits */
 #define PTGPU_MAX_BOUNCES_PATH 62 /* non-branching kernel (LDS material stack) */
 #define PTGPU_MAX_BOUNCES_TREE 14 /* branching kernel (per-lane frame stack) */
@@ -121,6 +126,9 @@ typedef struct ptgpu_stats {
     uint64_t samples;     /* per_pixel-equivalent samples finished */
     uint64_t wave_iters;  /* sum over wavefronts of bounce-loop iterations */
     uint64_t launches;    /* megakernel launches */
+    uint64_t scans;       /* closest-hit scans of the scene actually executed.
+                             Equals `rays` unless the primary segment's scan
+                             was shared between the samples of a pixel */
 } ptgpu_stats;
 
 /* Opaque device-resident scene (geometry + materials in HBM, laid out for the

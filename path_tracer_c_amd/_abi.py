@@ -37,6 +37,7 @@ FLAG_SCAN_PLAIN = 0x10
 FLAG_SCENE_LDS = 0x40
 FLAG_PIXEL_OWNER = 0x80
 FLAG_SAMPLE_QUEUE = 0x100
+FLAG_NO_PRIMARY_SHARE = 0x200
 FLAG_SCAN_SCREENED = 0x20
 
 MAX_BOUNCES_PATH = 62
@@ -149,7 +150,8 @@ class Params(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64),
-                ("wave_iters", C.c_uint64), ("launches", C.c_uint64)]
+                ("wave_iters", C.c_uint64), ("launches", C.c_uint64),
+                ("scans", C.c_uint64)]
 
 
 assert C.sizeof(Vec3) == 12 and C.sizeof(Sphere) == 16

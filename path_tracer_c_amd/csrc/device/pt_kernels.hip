@@ -121,8 +121,28 @@ __device__ __forceinline__ V3 shade_level(const F4 m0, const F4 m1, V3 child) {
 // The host picks settle_lanes from the scene size (a pass over 1000 objects
 // dwarfs a settle; a pass over 8 does not).  The image does not depend on it.
 // ---------------------------------------------------------------------------
+// Diagnostic build only (make EXTRA_HIPFLAGS=-DPT_STAMPS): wave-level cycle
+// shares of the scene scan, the shading and the settle stage, summed into
+// three device words that no kernel reads and no output depends on
+// (tools/stamps.py prints them).  The shipped library contains no stamp.
+#ifdef PT_STAMPS
+#define PT_STAMP(var)                                                          \
+    unsigned long long var;                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");  \
+    __builtin_amdgcn_sched_barrier(0)
+#define PT_STAMP_ADD(field, later, earlier) (field) += (later) - (earlier)
+__device__ unsigned long long g_stamps[4];
+#else
+#define PT_STAMP(var)
+#define PT_STAMP_ADD(field, later, earlier)
+#endif
+
 // State of one lane's path.
 struct PathState {
+#ifdef PT_STAMPS
+    unsigned long long t_scan = 0, t_shade = 0, t_settle = 0, t_total = 0;
+#endif
     V3 o, d;        // ray to trace next
     V3 r;           // value returned by the deepest call, once parked
     uint32_t depth; // hits recorded on the bounce stack so far
@@ -135,12 +155,21 @@ struct PathState {
 // either end the path (miss, depth limit, total internal reflection) or
 // produce the next ray (src/renderer.c:24-70).
 template <bool kScreen>
+__device__ __forceinline__ Hit scan_scene(const SceneRecords &rec, V3 o, V3 d,
+                                          const ScreenQueue queue) {
+    return kScreen ? closest_hit_screened(rec, o, d, queue) : closest_hit(rec, o, d);
+}
+
+// `known` (wave-uniform): the closest hit of p's ray is already in `h_known`.
+template <bool kScreen>
 __device__ __forceinline__ void
 advance_path(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
              uint32_t stack_stride, const ScreenQueue queue, V3 sky,
-             PathState &p) {
-    const Hit h = kScreen ? closest_hit_screened(rec, p.o, p.d, queue)
-                          : closest_hit(rec, p.o, p.d);
+             PathState &p, bool known = false, Hit h_known = Hit{-1.0f, -1}) {
+    PT_STAMP(stamp0);
+    const Hit h = known ? h_known : scan_scene<kScreen>(rec, p.o, p.d, queue);
+    PT_STAMP(stamp1);
+    PT_STAMP_ADD(p.t_scan, stamp1, stamp0);
     if (h.distance < 0.0f) { // miss: this level returns the sky colour
         p.r = sky;
         p.live = false;
@@ -175,6 +204,8 @@ advance_path(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
         }
     }
     p.parked = !p.live;
+    PT_STAMP(stamp2);
+    PT_STAMP_ADD(p.t_shade, stamp2, stamp1);
 }
 
 // The unwind of a parked lane: re-apply Le + lerp(refl, trans, t) * albedo
@@ -205,7 +236,8 @@ template <bool kScreen>
 __device__ __forceinline__ void
 run_paths(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
           uint32_t stack_stride, const ScreenQueue queue, V3 d0, uint32_t pixel,
-          uint32_t spp, V3 sky, V3 &sum, uint32_t &rays, uint32_t &iters) {
+          uint32_t spp, V3 sky, V3 &sum, uint32_t &rays, uint32_t &scans,
+          uint32_t &iters) {
     uint32_t s = 0;
     PathState p;
     p.o = splat(0.0f);
@@ -216,12 +248,31 @@ run_paths(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
     p.live = s < spp;
     p.parked = false;
 
+    // Every sample of a pixel starts with the same un-jittered primary ray
+    // (src/renderer.c:96-100 computes x, y once per pixel), so its closest hit
+    // is the same: scan for it once.  The stored hit is used only on passes
+    // where every live lane of the wave is at a path's first segment -- a
+    // wave-uniform test, true at the start of nearly every sample when the
+    // wave's paths have equal lengths (closed scenes) -- otherwise the scan
+    // runs anyway for the other lanes and sharing would save nothing.
+    Hit h_primary = Hit{-1.0f, -1};
+    if (a.share_primary && p.live) {
+        h_primary = scan_scene<kScreen>(rec, p.o, p.d, queue);
+        ++scans;
+    }
+
+    PT_STAMP(begin);
     while (__any(p.live || p.parked)) {
         ++iters;
+        const bool all_at_start = a.share_primary && !__any(p.live && p.depth != 0u);
         if (p.live) {
             ++rays;
-            advance_path<kScreen>(rec, a, stack, stack_stride, queue, sky, p);
+            if (!all_at_start)
+                ++scans;
+            advance_path<kScreen>(rec, a, stack, stack_stride, queue, sky, p,
+                                  all_at_start, h_primary);
         }
+        PT_STAMP(settle0);
         if (settle_now(p.live, p.parked, a.settle_lanes)) {
             if (p.parked) {
                 sum = sum + unwind_path(rec, stack, stack_stride, p);
@@ -234,7 +285,18 @@ run_paths(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
                 p.live = s < spp;
             }
         }
+        PT_STAMP(settle1);
+        PT_STAMP_ADD(p.t_settle, settle1, settle0);
     }
+#ifdef PT_STAMPS
+    PT_STAMP(end);
+    if ((threadIdx.x & 63u) == 0u) {
+        atomicAdd(&g_stamps[0], p.t_scan);
+        atomicAdd(&g_stamps[1], p.t_shade);
+        atomicAdd(&g_stamps[2], p.t_settle);
+        atomicAdd(&g_stamps[3], end - begin);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -482,15 +544,17 @@ __device__ __forceinline__ void store_rgb8(uint8_t *frame, V3 sum, float samples
 }
 
 __device__ __forceinline__ void count_wave(Counters *c, uint32_t rays,
-                                           uint32_t samples, uint32_t iters,
-                                           uint32_t lane) {
+                                           uint32_t scans, uint32_t samples,
+                                           uint32_t iters, uint32_t lane) {
     if (c == nullptr)
         return;
     const uint32_t wrays = wave_sum(rays);
+    const uint32_t wscans = wave_sum(scans);
     const uint32_t wsamples = wave_sum(samples);
     const uint32_t witers = wave_max(iters);
     if (lane == 0u) {
         atomicAdd(&c->rays, (unsigned long long)wrays);
+        atomicAdd(&c->scans, (unsigned long long)wscans);
         atomicAdd(&c->samples, (unsigned long long)wsamples);
         atomicAdd(&c->wave_iters, (unsigned long long)witers);
     }
@@ -521,13 +585,15 @@ __global__ void __launch_bounds__(1024) pt_megakernel(const LaunchArgs a) {
         sum = V3{prev.x, prev.y, prev.z};
         had = prev.w;
     }
-    uint32_t rays = 0, iters = 0;
+    uint32_t rays = 0, scans = 0, iters = 0;
     const uint32_t spp = valid ? a.spp : 0u;
-    if (kTree)
+    if (kTree) {
         run_tree(w.rec, a, ps.d0, ps.pixel, spp, sky, sum, rays, iters);
-    else
+        scans = rays;
+    } else {
         run_paths<kScreen>(w.rec, a, w.stack, nthreads, w.queue, ps.d0, ps.pixel,
-                           spp, sky, sum, rays, iters);
+                           spp, sky, sum, rays, scans, iters);
+    }
 
     // ---- write back ------------------------------------------------------------
     if (a.accum != nullptr) {
@@ -537,7 +603,7 @@ __global__ void __launch_bounds__(1024) pt_megakernel(const LaunchArgs a) {
     } else {
         store_rgb8(a.frame, sum, (float)a.spp, ps.out_pixel, valid, tid & 63u);
     }
-    count_wave(a.counters, rays, spp, iters, tid & 63u);
+    count_wave(a.counters, rays, scans, spp, iters, tid & 63u);
 }
 
 // ---------------------------------------------------------------------------
@@ -671,7 +737,7 @@ __global__ void __launch_bounds__(1024)
             }
         }
     }
-    count_wave(a.counters, rays, done, iters, lane);
+    count_wave(a.counters, rays, rays, done, iters, lane);
 }
 
 // Adds the `spp` buffered samples of each pixel, in sample order, onto the
@@ -887,6 +953,19 @@ hipError_t launch_sum(const LaunchArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL(pt_sum_kernel, dim3(grid), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
+
+#ifdef PT_STAMPS
+extern "C" int ptgpu_debug_stamps(unsigned long long out[4], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 4) != hipSuccess)
+        return -1;
+    if (reset) {
+        unsigned long long zero[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof zero) != hipSuccess)
+            return -1;
+    }
+    return 0;
+}
+#endif
 
 hipError_t launch_resolve(const float *accum, uint8_t *frame, uint64_t npixels,
                           hipStream_t stream) {

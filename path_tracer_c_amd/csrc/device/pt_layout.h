@@ -70,6 +70,7 @@ struct Counters { // device-side statistics, one instance per device
     unsigned long long samples;
     unsigned long long wave_iters;
     unsigned long long launches;
+    unsigned long long scans; // closest-hit scans executed (<= rays)
 };
 
 struct LaunchArgs {
@@ -86,6 +87,7 @@ struct LaunchArgs {
     uint32_t scene_in_lds;
     uint32_t screened;     // large scene: screen + per-lane queue (pt_trace.h)
     uint32_t settle_lanes; // parked lanes that trigger a settle stage (1..64)
+    uint32_t share_primary; // pixel-owner kernel: scan the primary ray once per pixel
     // sample-queue mode (pt_samplekernel / pt_sum_kernel)
     float *sample_buf;       // float4 per task: [sample][npix_pad]
     uint32_t *chunk_counter; // next chunk of 64 tasks; zeroed before a launch

@@ -446,6 +446,7 @@ int prepare_launch(const ptgpu_scene *s, size_t framew, size_t frameh,
         a->screened = 0u;
     if (p->flags & PTGPU_FLAG_SCAN_SCREENED)
         a->screened = 1u;
+    a->share_primary = (p->flags & PTGPU_FLAG_NO_PRIMARY_SHARE) ? 0u : 1u;
     if (p->settle_lanes > 64u)
         return fail(PTGPU_ERR_INVALID, "settle_lanes must be 0..64");
     a->settle_lanes = p->settle_lanes ? p->settle_lanes : auto_settle_lanes(s->desc);
@@ -1007,6 +1008,7 @@ int ptgpu_stats_read(ptgpu_stats *out) {
     out->rays = host.rays;
     out->samples = host.samples;
     out->wave_iters = host.wave_iters;
+    out->scans = host.scans;
     int dev = 0;
     out->launches = (current_device(&dev) == PTGPU_OK) ? g_launches[dev].load() : 0;
     return PTGPU_OK;

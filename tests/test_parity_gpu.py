@@ -417,6 +417,25 @@ def test_legacy_frame_over_several_devices(gpu, oracle, monkeypatch):
     assert np.array_equal(got, ref)
 
 
+def test_primary_scan_sharing_is_invisible_and_accounted(gpu, oracle):
+    """Sharing the primary-ray scan between a pixel's samples (default) or not
+    (PTGPU_FLAG_NO_PRIMARY_SHARE) gives the same frame; `rays` counts path
+    segments either way, `scans` the scene scans actually executed."""
+    w, h, spp = 128, 72, 16
+    with gpu.HostScene(2) as s:
+        ref, rays = oracle.render_rows(s, w, h, spp=spp, max_bounces=8, seed=6)
+        gpu.host.reset_stats()
+        shared = gpu.render_frame(s, w, h, spp=spp, max_bounces=8, seed=6, flags=0x80)
+        st_shared = gpu.host.read_stats()
+        gpu.host.reset_stats()
+        plain = gpu.render_frame(s, w, h, spp=spp, max_bounces=8, seed=6, flags=0x280)
+        st_plain = gpu.host.read_stats()
+    assert np.array_equal(shared, ref) and np.array_equal(plain, ref)
+    assert st_shared.rays == rays and st_plain.rays == rays
+    assert st_plain.scans == rays
+    assert w * h <= rays - st_shared.scans <= w * h * (spp - 1)   # at most one scan saved per sample
+
+
 def test_same_seed_same_bytes_other_seed_other_bytes(gpu):
     with gpu.HostScene(2) as s:
         a = gpu.render_frame(s, 128, 72, spp=8, max_bounces=8, seed=1)

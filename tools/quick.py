@@ -1,7 +1,10 @@
 import sys
 sys.path.insert(0, '.')
 from tools.sweep_settle import run
-for i in range(2):
-    run('c2', flags=0x80)
-run('c0', flags=0x80)
-run('c1', w=1920, h=1080, spp=256, flags=0x80)
+import path_tracer_c_amd as pt
+for flags in (0x80, 0x280, 0x80):
+    for settle in (0, 64):
+        run('c2', flags=flags, settle=settle)
+        st = pt.host.read_stats(); print("   scans/rays", st.scans / st.rays)
+run('c0', flags=0x80); run('c0', flags=0x280)
+run('c5', spp=32, flags=0x80); run('c5', spp=32, flags=0x280)
