@@ -436,6 +436,75 @@ def test_primary_scan_sharing_is_invisible_and_accounted(gpu, oracle):
     assert w * h <= rays - st_shared.scans <= w * h * (spp - 1)   # at most one scan saved per sample
 
 
+def _random_scene(gpu, rng, branching):
+    """A hostile random scene: any object count, scales from 1e-3 to 1e4,
+    zero / huge / negative radii, camera inside spheres, slivers, roughness
+    above 1, emission, every transparency class."""
+    s = gpu.HostScene()
+    s.set_sky(*rng.uniform(0, 1.2, 3))
+    scale = float(10 ** rng.uniform(-3, 4))
+    n_mat = int(rng.integers(1, 9))
+    t_choices = [0.0, 0.0, 0.0, 1.0, 1.0, -0.3, 1.7] + ([0.5, 0.25, 0.9] if branching else [])
+    for _ in range(n_mat):
+        s.add_material(tuple(rng.uniform(0, 1.1, 3)), roughness=float(rng.choice([0.0, 0.1, 0.5, 1.0, 2.0])),
+                       emission_color=tuple(rng.uniform(0, 1, 3)),
+                       emission_strength=float(rng.choice([0.0, 0.0, 1.0, 10.0])),
+                       transparency=float(rng.choice(t_choices)), refractive_index=1.5)
+    n_obj = int(rng.choice([1, 2, 5, 9, 31, 32, 33, 70]))
+    for _ in range(n_obj):
+        c = rng.normal(0, 3, 3) * scale + np.array([0, 0, 4 * scale])
+        m = int(rng.integers(n_mat))
+        kind = rng.integers(10)
+        if kind < 6:
+            r = float(rng.choice([0.0, 0.3, 1.0, 3.0, 50.0, -0.7])) * scale
+            s.add_sphere(tuple(c), r, m)
+        elif kind < 9:
+            e1 = rng.normal(0, 2, 3) * scale
+            e2 = rng.normal(0, 2, 3) * scale
+            s.add_triangle(tuple(c), tuple(c + e1), tuple(c + e2), m)
+        else:                                       # sliver / degenerate triangle
+            e1 = rng.normal(0, 2, 3) * scale
+            s.add_triangle(tuple(c), tuple(c + e1), tuple(c + e1 * (1 + 1e-6)), m)
+    if rng.integers(3) == 0:                        # camera inside a big sphere
+        s.add_sphere((0, 0, 0), 20.0 * scale, int(rng.integers(n_mat)))
+    return s
+
+
+@pytest.mark.parametrize("branching", [False, True], ids=["paths", "trees"])
+def test_randomised_scenes_match_the_oracle(gpu, oracle, branching):
+    rng = np.random.default_rng(2025 + int(branching))
+    for trial in range(40 if not branching else 16):
+        with _random_scene(gpu, rng, branching) as s:
+            w, h = int(rng.integers(8, 70)), int(rng.integers(5, 40))
+            spp = int(rng.integers(1, 5))
+            b = int(rng.integers(0, 11 if not branching else 5))
+            flags = int(rng.choice([0, 0x40, 0x100, 0x20, 0x10, 0x140])) if not branching else int(rng.choice([0, 0x40]))
+            got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=trial, flags=flags)
+            ref, _ = oracle.render_rows(s, w, h, spp=spp, max_bounces=b, seed=trial)
+            assert np.array_equal(got, ref), (trial, w, h, spp, b, hex(flags), s.counts())
+
+
+def test_kernel_limits_at_their_maximum(gpu, oracle):
+    """The deepest bounce stacks the two kernels accept (62 and 14)."""
+    with mirror_room(gpu) as s:
+        got = gpu.render_frame(s, 24, 16, spp=2, max_bounces=62, flags=0x80)
+        ref, rays = oracle.render_rows(s, 24, 16, spp=2, max_bounces=62)
+        assert rays == 24 * 16 * 2 * 63 and np.array_equal(got, ref)
+        got = gpu.render_frame(s, 24, 16, spp=2, max_bounces=62, flags=0x100, block_threads=1024)
+        assert np.array_equal(got, ref)
+        got = gpu.render_frame(s, 24, 16, spp=2, max_bounces=14, flags=0x4)
+        ref, _ = oracle.render_rows(s, 24, 16, spp=2, max_bounces=14)
+        assert np.array_equal(got, ref)
+
+
+def mirror_room(gpu):
+    s = gpu.HostScene()
+    s.set_sky(0.9, 0.8, 0.7)
+    m = s.add_material((0.97, 0.97, 0.97), roughness=0.0)
+    s.add_sphere((0, 0, 0), 10.0, m)
+    return s
+
+
 def test_same_seed_same_bytes_other_seed_other_bytes(gpu):
     with gpu.HostScene(2) as s:
         a = gpu.render_frame(s, 128, 72, spp=8, max_bounces=8, seed=1)
