@@ -84,6 +84,12 @@ extern "C" {
                                          stream once) and remembers the
                                          choice in the ptgpu_scene. */
 
+#define PTGPU_FLAG_SCAN_BVH 0x400u     /* scheduling only: walk a bounding-volume
+                                         hierarchy (built at upload for >= 64
+                                         objects; default for >= 768) instead
+                                         of scanning every object.  Candidates
+                                         still get the reference's exact tests
+                                         and accept rule: same image */
 #define PTGPU_FLAG_NO_PRIMARY_SHARE 0x200u /* scheduling only: scan the scene
                                          for the primary ray of every sample,
                                          as the reference does, instead of once
@@ -206,6 +212,12 @@ int ptgpu_device_synchronize(void);
 /* origins/directions: n x 3 floats; hits: n ray_hit records. */
 int ptgpu_trace_rays(const scene *host_scene, const float *origins,
                      const float *directions, size_t n, ray_hit *hits);
+/* The same query through a chosen scan form: scan_flags = 0 (plain, what
+ * ptgpu_trace_rays uses), PTGPU_FLAG_SCAN_SCREENED or PTGPU_FLAG_SCAN_BVH.
+ * All three return the same hits. */
+int ptgpu_trace_rays_scan(const scene *host_scene, const float *origins,
+                          const float *directions, size_t n, ray_hit *hits,
+                          uint32_t scan_flags);
 
 /* -- bookkeeping ------------------------------------------------------------ */
 int ptgpu_stats_reset(void);

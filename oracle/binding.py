@@ -60,6 +60,10 @@ def lib():
         h.oracle_sample.argtypes = [C.POINTER(Scene), C.c_size_t, C.c_size_t,
                                     C.c_int, C.c_int, C.c_uint32,
                                     C.POINTER(OracleParams), C.c_void_p]
+        h.oracle_sample_rays.restype = C.c_size_t
+        h.oracle_sample_rays.argtypes = [C.POINTER(Scene), C.c_size_t, C.c_size_t,
+                                         C.c_int, C.c_int, C.c_uint32,
+                                         C.POINTER(OracleParams), C.c_void_p, C.c_size_t]
         h.oracle_srandom.restype = None
         h.oracle_srandom.argtypes = [C.c_uint]
         h.oracle_render_mt.restype = C.c_uint64
@@ -134,3 +138,12 @@ def sample(scene, width, height, sx, sy, index, **kw):
     lib().oracle_sample(scene.ptr(), width, height, sx, sy, index, C.byref(p),
                         C.cast(out, C.c_void_p))
     return np.array(out[:], dtype=np.float32)
+
+
+def sample_rays(scene, width, height, sx, sy, index, max_rays=64, **kw):
+    """(origins, directions) of every trace_ray call of one sample."""
+    p = params(**kw)
+    buf = np.zeros((max_rays, 6), dtype=np.float32)
+    n = lib().oracle_sample_rays(scene.ptr(), width, height, sx, sy, index, C.byref(p),
+                                 buf.ctypes.data_as(C.c_void_p), max_rays)
+    return buf[:n, :3].copy(), buf[:n, 3:].copy()

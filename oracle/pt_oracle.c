@@ -44,6 +44,8 @@ typedef struct {
     uint32_t state;      /* xorshift state of the current sample */
     uint32_t max_bounces;
     uint64_t rays;       /* trace_ray calls made through this context */
+    float *record;       /* optional: 6 floats (origin, direction) per trace_ray call */
+    size_t record_cap, record_n;
 } path_ctx;
 
 /* ---- src/ray.c:4-73 ------------------------------------------------------- */
@@ -143,6 +145,11 @@ static vec3s incident_light(path_ctx *c, vec3s origin, vec3s direction,
     bounces++;
 
     c->rays++;
+    if (c->record != NULL && c->record_n < c->record_cap) {
+        float *r = c->record + 6 * c->record_n++;
+        r[0] = origin.x; r[1] = origin.y; r[2] = origin.z;
+        r[3] = direction.x; r[4] = direction.y; r[5] = direction.z;
+    }
     ray_hit hit = trace_closest(origin, direction, world);
     if (hit.distance < 0.0f)
         return world->sky_color;
@@ -218,7 +225,7 @@ static vec3s pixel_sum(path_ctx *c, const scene *world, size_t w, size_t h,
 /* ---- src/renderer.c:92-116: one image row ---------------------------------- */
 static uint64_t render_row(const scene *world, uint8_t *frame, size_t w,
                            size_t h, int sy, const oracle_params *p) {
-    path_ctx c = {p->rng_mode, 0u, p->max_bounces, 0u};
+    path_ctx c = {p->rng_mode, 0u, p->max_bounces, 0u, NULL, 0, 0};
     for (int sx = 0; sx < (int)w; sx++) {
         vec3s result = pixel_sum(&c, world, w, h, sx, sy, p, om_zero());
         result = om_scale(result, 1.0f / (float)p->spp * 255.0f);
@@ -242,7 +249,7 @@ uint64_t oracle_render_rows(const scene *world, uint8_t *frame, size_t w,
 uint64_t oracle_accumulate_rows(const scene *world, float *accum, size_t w,
                                 size_t h, size_t row_begin, size_t row_end,
                                 const oracle_params *p) {
-    path_ctx c = {p->rng_mode, 0u, p->max_bounces, 0u};
+    path_ctx c = {p->rng_mode, 0u, p->max_bounces, 0u, NULL, 0, 0};
     for (size_t y = row_begin; y < row_end && y < h; y++) {
         for (size_t sx = 0; sx < w; sx++) {
             float *px = accum + 4 * (y * w + sx);
@@ -259,7 +266,7 @@ uint64_t oracle_accumulate_rows(const scene *world, float *accum, size_t w,
 
 void oracle_sample(const scene *world, size_t w, size_t h, int sx, int sy,
                    uint32_t sample, const oracle_params *p, float out_rgb[3]) {
-    path_ctx c = {p->rng_mode, 0u, p->max_bounces, 0u};
+    path_ctx c = {p->rng_mode, 0u, p->max_bounces, 0u, NULL, 0, 0};
     oracle_params one = *p;
     one.spp = 1;
     one.sample_offset = sample;
@@ -267,6 +274,17 @@ void oracle_sample(const scene *world, size_t w, size_t h, int sx, int sy,
     out_rgb[0] = s.x;
     out_rgb[1] = s.y;
     out_rgb[2] = s.z;
+}
+
+size_t oracle_sample_rays(const scene *world, size_t w, size_t h, int sx, int sy,
+                          uint32_t sample, const oracle_params *p, float *rays6,
+                          size_t max_rays) {
+    path_ctx c = {p->rng_mode, 0u, p->max_bounces, 0u, rays6, max_rays, 0};
+    oracle_params one = *p;
+    one.spp = 1;
+    one.sample_offset = sample;
+    (void)pixel_sum(&c, world, w, h, sx, sy, &one, om_zero());
+    return c.record_n;
 }
 
 void oracle_srandom(unsigned int seed) { srandom(seed); }

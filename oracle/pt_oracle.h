@@ -43,6 +43,12 @@ uint64_t oracle_accumulate_rows(const scene *world, float *accum, size_t w,
 void oracle_sample(const scene *world, size_t w, size_t h, int sx, int sy,
                    uint32_t sample, const oracle_params *p, float out_rgb[3]);
 
+/* The rays (origin xyz, direction xyz) of every trace_ray call that sample
+ * makes, in call order; returns their number (debugging aid for the tests). */
+size_t oracle_sample_rays(const scene *world, size_t w, size_t h, int sx, int sy,
+                          uint32_t sample, const oracle_params *p, float *rays6,
+                          size_t max_rays);
+
 /* srandom(), for RNG_LIBC runs (src/main.c:140 seeds with time(NULL)). */
 void oracle_srandom(unsigned int seed);
 

@@ -38,6 +38,7 @@ FLAG_SCENE_LDS = 0x40
 FLAG_PIXEL_OWNER = 0x80
 FLAG_SAMPLE_QUEUE = 0x100
 FLAG_NO_PRIMARY_SHARE = 0x200
+FLAG_SCAN_BVH = 0x400
 FLAG_SCAN_SCREENED = 0x20
 
 MAX_BOUNCES_PATH = 62
@@ -214,6 +215,8 @@ SIGNATURES = {
                                        C.c_void_p]),
     "ptgpu_trace_rays": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.c_void_p]),
+    "ptgpu_trace_rays_scan": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_void_p,
+                                        C.c_size_t, C.c_void_p, C.c_uint32]),
     "ptgpu_stats_reset": (C.c_int, []),
     "ptgpu_stats_read": (C.c_int, [C.POINTER(Stats)]),
     "ptgpu_last_error": (C.c_char_p, []),

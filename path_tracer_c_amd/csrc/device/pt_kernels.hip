@@ -154,20 +154,25 @@ struct PathState {
 // One recursion level of incident_light for a live lane: scan the scene, then
 // either end the path (miss, depth limit, total internal reflection) or
 // produce the next ray (src/renderer.c:24-70).
-template <bool kScreen>
+// kScan: 0 plain linear scan, 1 screened linear scan, 2 BVH scan.
+template <int kScan>
 __device__ __forceinline__ Hit scan_scene(const SceneRecords &rec, V3 o, V3 d,
                                           const ScreenQueue queue) {
-    return kScreen ? closest_hit_screened(rec, o, d, queue) : closest_hit(rec, o, d);
+    if (kScan == 2)
+        return closest_hit_bvh(rec, o, d, queue);
+    if (kScan == 1)
+        return closest_hit_screened(rec, o, d, queue);
+    return closest_hit(rec, o, d);
 }
 
 // `known` (wave-uniform): the closest hit of p's ray is already in `h_known`.
-template <bool kScreen>
+template <int kScan>
 __device__ __forceinline__ void
 advance_path(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
              uint32_t stack_stride, const ScreenQueue queue, V3 sky,
              PathState &p, bool known = false, Hit h_known = Hit{-1.0f, -1}) {
     PT_STAMP(stamp0);
-    const Hit h = known ? h_known : scan_scene<kScreen>(rec, p.o, p.d, queue);
+    const Hit h = known ? h_known : scan_scene<kScan>(rec, p.o, p.d, queue);
     PT_STAMP(stamp1);
     PT_STAMP_ADD(p.t_scan, stamp1, stamp0);
     if (h.distance < 0.0f) { // miss: this level returns the sky colour
@@ -232,7 +237,7 @@ __device__ __forceinline__ bool settle_now(bool live, bool parked,
            (live_mask == 0ull || (uint32_t)__popcll(parked_mask) >= settle_lanes);
 }
 
-template <bool kScreen>
+template <int kScan>
 __device__ __forceinline__ void
 run_paths(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
           uint32_t stack_stride, const ScreenQueue queue, V3 d0, uint32_t pixel,
@@ -257,7 +262,7 @@ run_paths(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
     // runs anyway for the other lanes and sharing would save nothing.
     Hit h_primary = Hit{-1.0f, -1};
     if (a.share_primary && p.live) {
-        h_primary = scan_scene<kScreen>(rec, p.o, p.d, queue);
+        h_primary = scan_scene<kScan>(rec, p.o, p.d, queue);
         ++scans;
     }
 
@@ -269,7 +274,7 @@ run_paths(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
             ++rays;
             if (!all_at_start)
                 ++scans;
-            advance_path<kScreen>(rec, a, stack, stack_stride, queue, sky, p,
+            advance_path<kScan>(rec, a, stack, stack_stride, queue, sky, p,
                                   all_at_start, h_primary);
         }
         PT_STAMP(settle0);
@@ -466,6 +471,11 @@ stage_scene(const LaunchArgs &a, uint4 *lds_dyn, uint32_t tid, uint32_t nthreads
         w.rec.meta = a.scene.meta;
         w.rec.link = a.scene.link;
     }
+    w.rec.bvh_nodes = a.scene.bvh_nodes;
+    w.rec.bvh_order = a.scene.bvh_order;
+    w.rec.bvh_unbounded = a.scene.bvh_unbounded;
+    w.rec.n_nodes = a.scene.n_nodes;
+    w.rec.n_unbounded = a.scene.n_unbounded;
     w.stack = reinterpret_cast<uint16_t *>(lds_dyn + lds_used16) + tid;
     // the candidate queues of the screened scan sit behind the bounce stack
     // (2 * nthreads * (max_bounces + 1) bytes, rounded up to 16)
@@ -563,7 +573,7 @@ __device__ __forceinline__ void count_wave(Counters *c, uint32_t rays,
 // ---------------------------------------------------------------------------
 // Kernel 1: one work-item per pixel (pixel-owner mode).
 // ---------------------------------------------------------------------------
-template <bool kLds, bool kTree, bool kScreen>
+template <bool kLds, bool kTree, int kScan>
 __global__ void __launch_bounds__(1024) pt_megakernel(const LaunchArgs a) {
     extern __shared__ uint4 lds_dyn[]; // 16-byte aligned base
     const uint32_t tid = threadIdx.x;
@@ -591,7 +601,7 @@ __global__ void __launch_bounds__(1024) pt_megakernel(const LaunchArgs a) {
         run_tree(w.rec, a, ps.d0, ps.pixel, spp, sky, sum, rays, iters);
         scans = rays;
     } else {
-        run_paths<kScreen>(w.rec, a, w.stack, nthreads, w.queue, ps.d0, ps.pixel,
+        run_paths<kScan>(w.rec, a, w.stack, nthreads, w.queue, ps.d0, ps.pixel,
                            spp, sky, sum, rays, scans, iters);
     }
 
@@ -628,7 +638,7 @@ constexpr uint32_t kChunkBatch = 32; // chunks of 64 tasks reserved per atomic
 // its loop, and without the no-alias guarantee the compiler must assume a
 // store may change the scene, which turns the wave-uniform scalar loads of
 // the object scan (s_load, constant cache) into 64-lane vector loads.
-template <bool kLds, bool kScreen>
+template <bool kLds, int kScan>
 __global__ void __launch_bounds__(1024)
     pt_samplekernel(const LaunchArgs a, const F4 *__restrict__ scene_geom,
                     const F4 *__restrict__ scene_tri,
@@ -723,7 +733,7 @@ __global__ void __launch_bounds__(1024)
         ++iters;
         if (p.live) {
             ++rays;
-            advance_path<kScreen>(w.rec, a, w.stack, nthreads, w.queue, sky, p);
+            advance_path<kScan>(w.rec, a, w.stack, nthreads, w.queue, sky, p);
         }
 
         // ---- settle parked lanes: unwind, emit the sample, free the lane ----------
@@ -813,11 +823,14 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-// One work-item per query ray: the batched trace_ray of include/ray.h:14-15.
+// One work-item per query ray: the batched trace_ray of include/ray.h:14-15,
+// through any of the three scan forms (kScan as in scan_scene).
+template <int kScan>
 __global__ void __launch_bounds__(256)
     pt_trace_kernel(const SceneDesc scene, const float *__restrict__ origins,
                     const float *__restrict__ directions, uint64_t n,
                     DeviceRayHit *__restrict__ hits) {
+    extern __shared__ uint4 lds_dyn[];
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // every lane walks the object loop (it is wave-uniform); lanes past the
     // end trace a dummy ray and store nothing
@@ -830,10 +843,18 @@ __global__ void __launch_bounds__(256)
     rec.meta = scene.meta;
     rec.link = scene.link;
     rec.n_obj = scene.n_obj;
+    rec.bvh_nodes = scene.bvh_nodes;
+    rec.bvh_order = scene.bvh_order;
+    rec.bvh_unbounded = scene.bvh_unbounded;
+    rec.n_nodes = scene.n_nodes;
+    rec.n_unbounded = scene.n_unbounded;
+    ScreenQueue queue;
+    queue.slot = reinterpret_cast<uint32_t *>(lds_dyn) + threadIdx.x;
+    queue.stride = blockDim.x;
     const V3 o = V3{origins[3 * at], origins[3 * at + 1], origins[3 * at + 2]};
     const V3 d = V3{directions[3 * at], directions[3 * at + 1],
                     directions[3 * at + 2]};
-    const Hit h = closest_hit(rec, o, d);
+    const Hit h = scan_scene<kScan>(rec, o, d, queue);
     DeviceRayHit out;
     out.distance = h.distance;
     out.point[0] = out.point[1] = out.point[2] = 0.0f;
@@ -857,11 +878,11 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------
 // Launchers (called from the C-ABI layer).
 // ---------------------------------------------------------------------------
-template <bool kLds, bool kTree, bool kScreen>
+template <bool kLds, bool kTree, int kScan>
 static hipError_t launch_variant(const LaunchArgs &a, uint32_t grid,
                                  uint32_t block, size_t lds_bytes,
                                  hipStream_t stream) {
-    auto kernel = pt_megakernel<kLds, kTree, kScreen>;
+    auto kernel = pt_megakernel<kLds, kTree, kScan>;
     if (lds_bytes > 64u * 1024u) {
         hipError_t e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(kernel),
@@ -894,22 +915,26 @@ hipError_t launch_megakernel(const LaunchArgs &a, uint32_t block, bool tree,
     const size_t lds = megakernel_lds_bytes(a, block, tree);
     if (tree)
         return a.scene_in_lds
-                   ? launch_variant<true, true, false>(a, grid, block, lds, stream)
-                   : launch_variant<false, true, false>(a, grid, block, lds, stream);
-    if (a.screened)
+                   ? launch_variant<true, true, 0>(a, grid, block, lds, stream)
+                   : launch_variant<false, true, 0>(a, grid, block, lds, stream);
+    if (a.screened == 2u)
         return a.scene_in_lds
-                   ? launch_variant<true, false, true>(a, grid, block, lds, stream)
-                   : launch_variant<false, false, true>(a, grid, block, lds, stream);
+                   ? launch_variant<true, false, 2>(a, grid, block, lds, stream)
+                   : launch_variant<false, false, 2>(a, grid, block, lds, stream);
+    if (a.screened == 1u)
+        return a.scene_in_lds
+                   ? launch_variant<true, false, 1>(a, grid, block, lds, stream)
+                   : launch_variant<false, false, 1>(a, grid, block, lds, stream);
     return a.scene_in_lds
-               ? launch_variant<true, false, false>(a, grid, block, lds, stream)
-               : launch_variant<false, false, false>(a, grid, block, lds, stream);
+               ? launch_variant<true, false, 0>(a, grid, block, lds, stream)
+               : launch_variant<false, false, 0>(a, grid, block, lds, stream);
 }
 
-template <bool kLds, bool kScreen>
+template <bool kLds, int kScan>
 static hipError_t launch_sample_variant(const LaunchArgs &a, uint32_t grid,
                                         uint32_t block, size_t lds_bytes,
                                         hipStream_t stream) {
-    auto kernel = pt_samplekernel<kLds, kScreen>;
+    auto kernel = pt_samplekernel<kLds, kScan>;
     if (lds_bytes > 64u * 1024u) {
         hipError_t e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(kernel),
@@ -936,13 +961,17 @@ hipError_t launch_samplekernel(const LaunchArgs &a, uint32_t block,
     if (grid == 0)
         grid = 1;
     const size_t lds = megakernel_lds_bytes(a, block, false);
-    if (a.screened)
+    if (a.screened == 2u)
         return a.scene_in_lds
-                   ? launch_sample_variant<true, true>(a, grid, block, lds, stream)
-                   : launch_sample_variant<false, true>(a, grid, block, lds, stream);
+                   ? launch_sample_variant<true, 2>(a, grid, block, lds, stream)
+                   : launch_sample_variant<false, 2>(a, grid, block, lds, stream);
+    if (a.screened == 1u)
+        return a.scene_in_lds
+                   ? launch_sample_variant<true, 1>(a, grid, block, lds, stream)
+                   : launch_sample_variant<false, 1>(a, grid, block, lds, stream);
     return a.scene_in_lds
-               ? launch_sample_variant<true, false>(a, grid, block, lds, stream)
-               : launch_sample_variant<false, false>(a, grid, block, lds, stream);
+               ? launch_sample_variant<true, 0>(a, grid, block, lds, stream)
+               : launch_sample_variant<false, 0>(a, grid, block, lds, stream);
 }
 
 hipError_t launch_sum(const LaunchArgs &a, hipStream_t stream) {
@@ -980,12 +1009,20 @@ hipError_t launch_resolve(const float *accum, uint8_t *frame, uint64_t npixels,
 
 hipError_t launch_trace(const SceneDesc &scene, const float *origins,
                         const float *directions, uint64_t n,
-                        DeviceRayHit *hits, hipStream_t stream) {
+                        DeviceRayHit *hits, int scan, hipStream_t stream) {
     if (n == 0)
         return hipSuccess;
     const uint32_t grid = (uint32_t)((n + 255u) / 256u);
-    hipLaunchKernelGGL(pt_trace_kernel, dim3(grid), dim3(256), 0, stream, scene,
-                       origins, directions, n, hits);
+    const size_t lds = (size_t)4 * 256u * kScreenQueue;
+    if (scan == 2)
+        hipLaunchKernelGGL(pt_trace_kernel<2>, dim3(grid), dim3(256), lds, stream,
+                           scene, origins, directions, n, hits);
+    else if (scan == 1)
+        hipLaunchKernelGGL(pt_trace_kernel<1>, dim3(grid), dim3(256), lds, stream,
+                           scene, origins, directions, n, hits);
+    else
+        hipLaunchKernelGGL(pt_trace_kernel<0>, dim3(grid), dim3(256), lds, stream,
+                           scene, origins, directions, n, hits);
     return hipGetLastError();
 }
 

@@ -30,8 +30,9 @@ hipError_t launch_samplekernel(const LaunchArgs &a, uint32_t block,
 hipError_t launch_sum(const LaunchArgs &a, hipStream_t stream);
 hipError_t launch_resolve(const float *accum, uint8_t *frame, uint64_t npixels,
                           hipStream_t stream);
+// scan: 0 plain, 1 screened linear, 2 BVH (the scene must have a hierarchy)
 hipError_t launch_trace(const SceneDesc &scene, const float *origins,
                         const float *directions, uint64_t n,
-                        DeviceRayHit *hits, hipStream_t stream);
+                        DeviceRayHit *hits, int scan, hipStream_t stream);
 
 } // namespace pt

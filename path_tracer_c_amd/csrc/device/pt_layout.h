@@ -49,6 +49,13 @@ struct SceneDesc {
     const F4 *mat;        // 2 * n_mat
     const uint32_t *meta; // n_obj
     const uint32_t *link; // n_obj
+    // optional hierarchy over the objects (csrc/bvh_build.hpp); n_nodes == 0
+    // when it was not built
+    const F4 *bvh_nodes;           // 2 * n_nodes
+    const uint32_t *bvh_order;     // object indices, leaf runs
+    const uint32_t *bvh_unbounded; // objects without a finite box
+    uint32_t n_nodes;
+    uint32_t n_unbounded;
     uint32_t n_obj;
     uint32_t n_tri;
     uint32_t n_mat;
@@ -85,7 +92,7 @@ struct LaunchArgs {
     uint32_t spp, sample_offset, max_bounces, seed;
     float tan_half_fov;
     uint32_t scene_in_lds;
-    uint32_t screened;     // large scene: screen + per-lane queue (pt_trace.h)
+    uint32_t screened;     // scan form: 0 plain, 1 screened linear, 2 BVH (pt_trace.h)
     uint32_t settle_lanes; // parked lanes that trigger a settle stage (1..64)
     uint32_t share_primary; // pixel-owner kernel: scan the primary ray once per pixel
     // sample-queue mode (pt_samplekernel / pt_sum_kernel)

@@ -27,6 +27,12 @@ struct SceneRecords {
     const uint32_t *meta;
     const uint32_t *link;
     uint32_t n_obj;
+    // hierarchy (always in global memory), see csrc/bvh_build.hpp
+    const F4 *bvh_nodes;
+    const uint32_t *bvh_order;
+    const uint32_t *bvh_unbounded;
+    uint32_t n_nodes;
+    uint32_t n_unbounded;
 };
 
 PT_HD V3 xyz(const F4 &r) { return V3{r.x, r.y, r.z}; }
@@ -205,6 +211,200 @@ __device__ __forceinline__ Hit closest_hit_screened(const SceneRecords &rec,
     for (; i < n; ++i)
         push(screen_keep(rec.geom[i], o, d), i);
     resolve();
+    return h;
+}
+
+// ---------------------------------------------------------------------------
+// BVH scan (not in the reference).
+//
+// The reference's accept rule walks the objects in index order:
+//     keep candidate i unless (dist_i >= closest && closest > 0).
+// Call a found candidate *positive* if dist > 0 and *degenerate* otherwise
+// (dist is +0, -0 or NaN: the ray starts on the surface -- e.g. `dpp - r*r`
+// rounds to exactly 0 next to a radius-1000 sphere, 0.3 % of configuration
+// 5's rays -- or a root is 0/0).  Working the rule through:
+//   * a degenerate candidate is always kept when met, and whatever found
+//     candidate comes next is kept too (closest > 0 is false);
+//   * between degenerates the rule is a running strict minimum.
+// Hence, with L = the highest index of a degenerate candidate (none: L = -1),
+// the walk returns the minimum-distance positive candidate among indices > L,
+// lowest index on ties, and if there is none, candidate L itself.  That is a
+// function of the candidate SET, so the hierarchy may deliver candidates in
+// any order: a lane tracks the global best positive (distance, lowest index)
+// and the highest degenerate index.  If the best positive lies beyond L it is
+// the answer; if L is the last object, L is; otherwise (rare) the lane walks
+// the hierarchy once more, considering only indices > L.
+//
+// Traversal is stackless (depth-first node order + skip links), one node per
+// lane per pass of the loop; a box test is a slab test with slack
+// proportional to the distances involved (the exact tests are themselves
+// only accurate to ~|c-o| * 2^-23, so a far-away ray must be allowed to "hit"
+// generously), and nodes wholly beyond the best exact distance so far are
+// skipped.  Leaf objects go through the conservative sphere screen into the
+// lane's LDS queue; exact tests run in dense resolve phases, as in the
+// screened scan.  Triangles can never be degenerate (their test demands
+// distance > 1e-6).
+// ---------------------------------------------------------------------------
+struct UnorderedBest {
+    float best;     // smallest positive distance so far
+    int best_idx;   // its object (lowest index among equals), -1: none
+    float deg_dist; // distance (+-0 / NaN) of the degenerate candidate ...
+    int deg_idx;    // ... with the highest index, -1: none
+};
+
+PT_HD void test_object_unordered(const SceneRecords &rec, V3 o, V3 d, uint32_t i,
+                                 const F4 g, UnorderedBest &u) {
+    float dist = 0.0f;
+    bool found;
+    if (!is_triangle_record(g)) {
+        float t1 = 0.0f, t2 = 0.0f;
+        found = ray_sphere(o, d, xyz(g), g.w, t1, t2);
+        dist = (t1 > 0.0f) ? t1 : t2;
+    } else {
+        const uint32_t k = rec.link[i];
+        const F4 v0 = rec.tri[4 * k + 0];
+        const F4 e1 = rec.tri[4 * k + 1];
+        const F4 e2 = rec.tri[4 * k + 2];
+        found = ray_triangle(o, d, xyz(v0), xyz(e1), xyz(e2), dist);
+    }
+    if (found) {
+        if (!(dist > 0.0f)) {
+            if ((int)i > u.deg_idx) {
+                u.deg_idx = (int)i;
+                u.deg_dist = dist;
+            }
+        } else if (dist < u.best || (dist == u.best && (int)i < u.best_idx)) {
+            u.best = dist;
+            u.best_idx = (int)i;
+        }
+    }
+}
+
+__device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3 d,
+                                               const ScreenQueue q) {
+    UnorderedBest u;
+    u.best = __builtin_inff();
+    u.best_idx = -1;
+    u.deg_dist = 0.0f;
+    u.deg_idx = -1;
+    uint32_t min_index = 0; // only objects with index >= min_index count
+    bool walking = true;    // this lane takes part in the current walk
+    uint32_t *const first = q.slot;
+    uint32_t *wr = first;
+    // a leaf adds at most kLeafMax = 4 entries, so resolving once 8 of the 12
+    // slots are used would be enough; resolving earlier (PT_BVH_RESOLVE_AT
+    // entries) makes `best` known sooner, and nodes beyond it are skipped
+#ifndef PT_BVH_RESOLVE_AT
+#define PT_BVH_RESOLVE_AT 1u /* measured: 1 beats 0, 3 and 8 (C5 57 vs 58, 60, 62 ms) */
+#endif
+    uint32_t *const nearly_full = first + (PT_BVH_RESOLVE_AT) * q.stride;
+
+    auto resolve = [&]() {
+        for (uint32_t *rd = first; __any(rd < wr); rd += q.stride) {
+            if (rd < wr) {
+                const uint32_t idx = *rd;
+                test_object_unordered(rec, o, d, idx, rec.geom[idx], u);
+            }
+        }
+        wr = first;
+    };
+
+    // A ray with a NaN or infinite component is not a geometric object any
+    // more: the exact sphere test then "finds" spheres wherever its NaN
+    // comparisons fall through (src/ray.c's callers do produce such rays: a
+    // 0/0 root poisons the next ray of the path).  Boxes mean nothing for
+    // it, so such a lane does the reference's sequential walk instead.
+    // (the sum is non-finite iff some component is, or the sum overflows --
+    // then the fallback is merely slower, still exact)
+    const float probe = (fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) +
+                        (fabsf(d.x) + fabsf(d.y) + fabsf(d.z));
+    const bool poisoned = !(probe < __builtin_inff());
+    walking = !poisoned;
+
+    const V3 inv = V3{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y),
+                      __builtin_amdgcn_rcpf(d.z)};
+    const uint32_t n = rec.n_nodes;
+    for (int walk = 0; walk < 2; ++walk) {
+        if (!__any(walking))
+            break;
+        for (uint32_t k = 0; k < rec.n_unbounded; ++k) {
+            const uint32_t idx = rec.bvh_unbounded[k];
+            if (walking && idx >= min_index) {
+                *wr = idx;
+                wr += q.stride;
+            }
+            if (__any(wr > nearly_full))
+                resolve();
+        }
+        uint32_t node = walking ? 0u : n;
+        while (__any(node < n)) {
+            if (node < n) {
+                const F4 lo = rec.bvh_nodes[2u * node + 0u];
+                const F4 hi = rec.bvh_nodes[2u * node + 1u];
+                const float x0 = (lo.x - o.x) * inv.x, x1 = (hi.x - o.x) * inv.x;
+                const float y0 = (lo.y - o.y) * inv.y, y1 = (hi.y - o.y) * inv.y;
+                const float z0 = (lo.z - o.z) * inv.z, z1 = (hi.z - o.z) * inv.z;
+                // fminf/fmaxf drop a NaN operand (0 * inf on a box face)
+                const float enter =
+                    fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+                const float leave =
+                    fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                const float slack = 1.0e-4f * (fabsf(enter) + fabsf(leave));
+                // written as "not certainly missed": every comparison is false
+                // for a NaN, so a ray with NaN components (they occur: a 0/0
+                // root makes the next ray NaN, and the sequential walk then
+                // "hits" every sphere) visits everything, as it must
+                const bool missed = (enter == __builtin_inff()) |
+                                    (leave == -__builtin_inff()) |
+                                    (leave - enter < -slack) | (leave < -slack) |
+                                    (enter - slack > u.best);
+                const bool crossed = !missed;
+                const uint32_t skip = __builtin_bit_cast(uint32_t, lo.w);
+                const uint32_t leaf = __builtin_bit_cast(uint32_t, hi.w);
+                if (crossed && leaf != 0u) {
+                    const uint32_t count = leaf >> 24;
+                    const uint32_t at = leaf & 0x00FFFFFFu;
+                    for (uint32_t k = 0; k < count; ++k) {
+                        const uint32_t idx = rec.bvh_order[at + k];
+                        if (idx >= min_index && screen_keep(rec.geom[idx], o, d)) {
+                            *wr = idx;
+                            wr += q.stride;
+                        }
+                    }
+                }
+                node = crossed ? node + 1u : skip; // a leaf's skip link is node + 1
+            }
+            if (__any(wr > nearly_full))
+                resolve();
+        }
+        resolve();
+        // second walk only for lanes whose answer lies beyond a degenerate hit
+        const bool again = walking && walk == 0 && u.deg_idx >= 0 &&
+                           u.best_idx < u.deg_idx &&
+                           (uint32_t)u.deg_idx + 1u < rec.n_obj;
+        if (again) {
+            min_index = (uint32_t)u.deg_idx + 1u;
+            u.best = __builtin_inff();
+            u.best_idx = -1;
+        }
+        walking = again;
+    }
+
+    Hit h;
+    if (u.best_idx >= 0 && u.best_idx > u.deg_idx) {
+        h.distance = u.best;
+        h.object = u.best_idx;
+    } else if (u.deg_idx >= 0) {
+        h.distance = u.deg_dist;
+        h.object = u.deg_idx;
+    } else {
+        h.distance = -1.0f;
+        h.object = -1;
+    }
+    if (__any(poisoned)) {
+        if (poisoned)
+            h = closest_hit(rec, o, d);
+    }
     return h;
 }
 

@@ -29,6 +29,7 @@
 #include <string>
 #include <vector>
 
+#include "bvh_build.hpp"
 #include "device/pt_launch.h"
 #include "device/pt_vec.h"
 #include "ptgpu.h"
@@ -59,6 +60,11 @@ int fail_hip(hipError_t e, const char *where) {
 
 constexpr int kMaxDevices = 64;
 constexpr size_t kLdsBudget = 160u * 1024u; // one workgroup may own it all
+constexpr uint32_t kBvhMinObjects = 64;      // a hierarchy is built from here up
+constexpr uint32_t kBvhAutoObjects = 768;    // and used by default from here up
+                                             // (measured: slower than the screened
+                                             // linear scan at 250 objects, 1.2x
+                                             // faster at 1000, 5.9x at 16000)
 
 // Per-device statistics block, allocated on first use.
 std::mutex g_ctx_mutex;
@@ -151,8 +157,9 @@ pt::F4 bounding_sphere_record(const triangle &t) {
 // The opaque handle of include/ptgpu.h.
 struct ptgpu_scene {
     int device;
-    void *blob;          // one allocation: geom | tri | mat | meta
+    void *blob;          // one allocation: geom | tri | mat | meta | link
     size_t blob_bytes;
+    void *bvh_blob = nullptr; // nodes | order | unbounded (large scenes only)
     pt::SceneDesc desc;  // device pointers into blob
     // Which schedule suits this scene, measured on its first large render:
     // -1 not measured yet, 0 pixel-owner kernel, 1 sample-queue kernels.
@@ -326,6 +333,38 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
                                                       4u * (size_t)n_tri +
                                                       2u * (size_t)n_mat);
     h->desc.link = h->desc.meta + n_obj;
+    h->desc.bvh_nodes = nullptr;
+    h->desc.bvh_order = nullptr;
+    h->desc.bvh_unbounded = nullptr;
+    h->desc.n_nodes = 0;
+    h->desc.n_unbounded = 0;
+    if (n_obj >= kBvhMinObjects) {
+        const pt::BvhHost bvh = pt::build_bvh(geom, n_obj);
+        const size_t node_bytes = bvh.nodes.size() * sizeof(pt::F4);
+        const size_t order_bytes = bvh.order.size() * sizeof(uint32_t);
+        const size_t unb_bytes = bvh.unbounded.size() * sizeof(uint32_t);
+        const size_t total = node_bytes + order_bytes + unb_bytes + 16;
+        std::vector<unsigned char> packed(total, 0);
+        std::memcpy(packed.data(), bvh.nodes.data(), node_bytes);
+        std::memcpy(packed.data() + node_bytes, bvh.order.data(), order_bytes);
+        std::memcpy(packed.data() + node_bytes + order_bytes, bvh.unbounded.data(), unb_bytes);
+        hipError_t be = hipMalloc(&h->bvh_blob, total);
+        if (be == hipSuccess)
+            be = hipMemcpy(h->bvh_blob, packed.data(), total, hipMemcpyHostToDevice);
+        if (be != hipSuccess) {
+            if (h->bvh_blob)
+                (void)hipFree(h->bvh_blob);
+            (void)hipFree(h->blob);
+            delete h;
+            return fail_hip(be, "hierarchy upload");
+        }
+        const unsigned char *b0 = static_cast<const unsigned char *>(h->bvh_blob);
+        h->desc.bvh_nodes = reinterpret_cast<const pt::F4 *>(b0);
+        h->desc.bvh_order = reinterpret_cast<const uint32_t *>(b0 + node_bytes);
+        h->desc.bvh_unbounded = reinterpret_cast<const uint32_t *>(b0 + node_bytes + order_bytes);
+        h->desc.n_nodes = (uint32_t)(bvh.nodes.size() / 2);
+        h->desc.n_unbounded = (uint32_t)bvh.unbounded.size();
+    }
     h->desc.n_obj = n_obj;
     h->desc.n_tri = n_tri;
     h->desc.n_mat = n_mat;
@@ -343,6 +382,8 @@ void ptgpu_scene_free(ptgpu_scene *s) {
         return;
     if (s->blob)
         (void)hipFree(s->blob);
+    if (s->bvh_blob)
+        (void)hipFree(s->bvh_blob);
     delete s;
 }
 
@@ -442,10 +483,17 @@ int prepare_launch(const ptgpu_scene *s, size_t framew, size_t frameh,
     a->tan_half_fov = tanf(p->fov_rad / 2.0f); // src/renderer.c:77
     a->scene_in_lds = want_lds ? 1u : 0u;
     a->screened = (s->desc.n_obj >= 32u) ? 1u : 0u;
+    if (s->desc.n_obj >= kBvhAutoObjects && s->desc.bvh_nodes != nullptr)
+        a->screened = 2u;
     if (p->flags & PTGPU_FLAG_SCAN_PLAIN)
         a->screened = 0u;
     if (p->flags & PTGPU_FLAG_SCAN_SCREENED)
         a->screened = 1u;
+    if (p->flags & PTGPU_FLAG_SCAN_BVH) {
+        if (s->desc.bvh_nodes == nullptr && s->desc.n_unbounded == 0)
+            return fail(PTGPU_ERR_INVALID, "scene has no hierarchy (fewer than 64 objects)");
+        a->screened = 2u;
+    }
     a->share_primary = (p->flags & PTGPU_FLAG_NO_PRIMARY_SHARE) ? 0u : 1u;
     if (p->settle_lanes > 64u)
         return fail(PTGPU_ERR_INVALID, "settle_lanes must be 0..64");
@@ -635,7 +683,8 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         const double util = lane_passes > 0 && rays > 0 ? rays / lane_passes : 1.0;
         const double rays_per_sample = samples > 0 ? rays / samples : 1.0;
         const double instr_per_ray =
-            (a.screened ? 16.0 : 80.0) * (double)a.scene.n_obj + 400.0;
+            (a.screened == 2u ? 4500.0 / std::max(1.0, (double)a.scene.n_obj)
+             : a.screened == 1u ? 16.0 : 80.0) * (double)a.scene.n_obj + 400.0;
         const double recovered = (1.0 / util - 1.0 / 0.99) * rays_per_sample * instr_per_ray;
         mode = recovered > 2.0 * 480.0 ? kSampleQueue : kPixelOwner;
         s->queue_mode.store(mode);
@@ -950,6 +999,12 @@ int ptgpu_device_synchronize(void) {
 // ---------------------------------------------------------------------------
 int ptgpu_trace_rays(const scene *host_scene, const float *origins,
                      const float *directions, size_t n, ray_hit *hits) {
+    return ptgpu_trace_rays_scan(host_scene, origins, directions, n, hits, 0);
+}
+
+int ptgpu_trace_rays_scan(const scene *host_scene, const float *origins,
+                          const float *directions, size_t n, ray_hit *hits,
+                          uint32_t scan_flags) {
     if (n == 0)
         return PTGPU_OK;
     if (origins == nullptr || directions == nullptr || hits == nullptr)
@@ -967,7 +1022,17 @@ int ptgpu_trace_rays(const scene *host_scene, const float *origins,
     if (e == hipSuccess) e = hipMalloc(&d_h, sizeof(pt::DeviceRayHit) * n);
     if (e == hipSuccess) e = hipMemcpy(d_o, origins, vec_bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_d, directions, vec_bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = pt::launch_trace(s->desc, d_o, d_d, n, d_h, nullptr);
+    int scan = 0;
+    if (scan_flags & PTGPU_FLAG_SCAN_SCREENED)
+        scan = 1;
+    if (scan_flags & PTGPU_FLAG_SCAN_BVH) {
+        if (s->desc.bvh_nodes == nullptr) {
+            ptgpu_scene_free(s);
+            return fail(PTGPU_ERR_INVALID, "scene has no hierarchy (fewer than 64 objects)");
+        }
+        scan = 2;
+    }
+    if (e == hipSuccess) e = pt::launch_trace(s->desc, d_o, d_d, n, d_h, scan, nullptr);
     if (e == hipSuccess)
         e = hipMemcpy(hits, d_h, sizeof(pt::DeviceRayHit) * n, hipMemcpyDeviceToHost);
     if (d_o) (void)hipFree(d_o);

@@ -136,15 +136,16 @@ def render_frame_legacy(scene: HostScene, width: int, height: int,
     return frame
 
 
-def trace_rays(scene: HostScene, origins, directions):
-    """Batched trace_ray: returns (distance, point, normal, material) arrays."""
+def trace_rays(scene: HostScene, origins, directions, scan_flags: int = 0):
+    """Batched trace_ray: returns (distance, point, normal, material) arrays.
+    scan_flags: 0 plain scan, FLAG_SCAN_SCREENED, FLAG_SCAN_BVH."""
     o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
     d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
     n = o.shape[0]
     hits = (RayHit * n)()
-    check(lib().ptgpu_trace_rays(scene.ptr(), o.ctypes.data_as(C.c_void_p),
-                                 d.ctypes.data_as(C.c_void_p), n,
-                                 C.cast(hits, C.c_void_p)))
+    check(lib().ptgpu_trace_rays_scan(scene.ptr(), o.ctypes.data_as(C.c_void_p),
+                                      d.ctypes.data_as(C.c_void_p), n,
+                                      C.cast(hits, C.c_void_p), scan_flags))
     return hits_to_arrays(hits, n)
 
 

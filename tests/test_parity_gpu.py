@@ -27,7 +27,7 @@ def bits(a):
 # ---- committed fixtures ---------------------------------------------------------
 @pytest.mark.parametrize("flags", [0, 0x40, 0x4, 0x44, 0x10, 0x20, 0x50, 0x60],
                          ids=["default", "lds", "tree", "lds+tree", "plain", "screened",
-                              "lds+plain", "lds+screened"])
+                              "lds+plain", "lds+screened"])  # (default = BVH scan for c5)
 @pytest.mark.parametrize("name", ["c1_64x64", "demo_80x50", "c2_96x54", "c5_48x27"])
 def test_golden_frames(gpu, name, flags):
     z = np.load(GOLDEN / f"frame_{name}.npz")
@@ -89,6 +89,43 @@ def test_random_rays_bit_equal_to_oracle(gpu, oracle):
         assert np.array_equal(bits(g[1][hit]), bits(c[1][hit]))
         assert np.array_equal(bits(g[2][hit]), bits(c[2][hit]))
         assert np.array_equal(g[3][hit], c[3][hit])
+
+
+def test_all_scan_forms_return_the_same_hits(gpu, oracle):
+    """Plain, screened and BVH scans through ptgpu_trace_rays_scan, on rays a
+    render really casts (eye rays, rays leaving surfaces by 0.001, rays that
+    start exactly on the radius-1000 ground sphere where `dpp - r*r` rounds to
+    0) and on poisoned rays (NaN / infinite components)."""
+    rng = np.random.default_rng(17)
+    with gpu.HostScene(5) as s:
+        n = 300000
+        d0 = rng.normal(size=(n, 3)).astype(f32)
+        d0[:, 2] = np.abs(d0[:, 2]) + 0.3
+        d0 /= np.linalg.norm(d0, axis=1, keepdims=True).astype(f32)
+        o0 = np.zeros((n, 3), f32)
+        first = gpu.trace_rays(s, o0, d0)
+        hit = first[0] >= 0
+        d1 = rng.normal(size=(int(hit.sum()), 3)).astype(f32)
+        d1 /= np.linalg.norm(d1, axis=1, keepdims=True).astype(f32)
+        o1 = (first[1][hit] + d1 * f32(0.001)).astype(f32)
+        o2 = first[1][hit].copy()                          # exactly on the surface
+        bad = np.array([[np.nan, 0, 1], [0, np.inf, 1], [0, 0, 0], [1e30, 1e30, 1e30]], dtype=f32)
+        o3 = np.zeros_like(bad)
+        o4 = np.tile(np.array([[np.nan, 1, 2]], dtype=f32), (4, 1))
+        for o, d in [(o0, d0), (o1, d1), (o2, d1), (o3, bad), (o4, bad)]:
+            plain = gpu.trace_rays(s, o, d)
+            ref = oracle.trace_rays(s, o[:2000], d[:2000])
+            a, b = plain[0][:2000], ref[0]                    # NaN payload/sign may differ CPU vs GPU
+            assert ((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))).all()
+            for flag in (gpu._abi.FLAG_SCAN_SCREENED, gpu._abi.FLAG_SCAN_BVH):
+                other = gpu.trace_rays(s, o, d, flag)
+                same = (bits(plain[0]) == bits(other[0])) | (np.isnan(plain[0]) & np.isnan(other[0]))
+                assert same.all(), (hex(flag), int((~same).sum()))
+                got = ~(plain[0] < 0)                        # hits, including distance -0 / NaN
+                assert np.array_equal(plain[3][got], other[3][got]), hex(flag)
+                fin = got & np.isfinite(plain[0])
+                assert np.array_equal(bits(plain[1][fin]), bits(other[1][fin]))
+                assert np.array_equal(bits(plain[2][fin]), bits(other[2][fin]))
 
 
 def test_legacy_trace_ray_single_query(gpu, oracle):
@@ -183,10 +220,13 @@ def test_limits_and_bad_arguments_are_reported(gpu):
 
 
 @pytest.mark.parametrize("settle", [1, 5, 64])
-@pytest.mark.parametrize("flags", [0x10, 0x20, 0x60], ids=["plain", "screened", "lds+screened"])
+@pytest.mark.parametrize("flags", [0x10, 0x20, 0x60, 0x400, 0x540],
+                         ids=["plain", "screened", "lds+screened", "bvh", "bvh+lds+queue"])
 def test_scheduling_knobs_never_change_the_image(gpu, oracle, flags, settle):
     """settle_lanes and the scan variant are scheduling only."""
     for cfg, w, h, spp, b in [(0, 96, 60, 6, 4), (5, 64, 36, 4, 8), (2, 64, 36, 4, 8)]:
+        if flags & 0x400 and cfg != 5:
+            continue                                 # hierarchy exists from 64 objects up
         with gpu.HostScene(cfg) as s:
             got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=13, flags=flags,
                                    settle_lanes=settle)
@@ -349,13 +389,44 @@ def test_triangle_mesh_is_screened_through_bounding_spheres(gpu, oracle):
             s.add_sphere(tuple(rng.uniform(-4, 4, 3) + np.array([0, 1.5, 8])), float(rng.uniform(0.3, 0.9)),
                          [shiny, glass, ground][int(rng.integers(3))])
         assert s.counts() == (12, 650)
-        got = gpu.render_frame(s, 112, 72, spp=4, max_bounces=5, seed=3)             # screened (default)
+        got = gpu.render_frame(s, 112, 72, spp=4, max_bounces=5, seed=3)             # BVH (default)
+        screened = gpu.render_frame(s, 112, 72, spp=4, max_bounces=5, seed=3, flags=0x20)
         plain = gpu.render_frame(s, 112, 72, spp=4, max_bounces=5, seed=3, flags=0x10)
         lds = gpu.render_frame(s, 112, 72, spp=4, max_bounces=5, seed=3, flags=0x140)  # lds + queue
         ref, _ = oracle.render_rows(s, 112, 72, spp=4, max_bounces=5, seed=3)
     assert np.array_equal(plain, ref)
+    assert np.array_equal(screened, ref)
     assert np.array_equal(got, ref)
     assert np.array_equal(lds, ref)
+
+
+def test_bvh_scan_falls_back_to_the_sequential_walk_on_degenerate_hits(gpu, oracle):
+    """The eye sits exactly ON a sphere's surface (a root of exactly 0): the
+    reference's accept rule then lets ANY later object replace that hit
+    (src/ray.c:25), which only the index-ordered walk reproduces.  Plus
+    objects without a finite bounding box, which the hierarchy cannot hold."""
+    rng = np.random.default_rng(8)
+    with gpu.HostScene() as s:
+        s.set_sky(0.3, 0.5, 0.8)
+        mats = [s.add_material(tuple(rng.uniform(0.3, 1, 3)), roughness=float(rng.uniform(0, 1)),
+                               emission_color=(1, 1, 1), emission_strength=float(i == 0))
+                for i in range(6)]
+        s.add_sphere((0, 0, -1), 1.0, mats[0])              # eye on its surface, leaving it
+        s.add_sphere((0, 0, 1), 1.0, mats[1])               # eye on its surface, entering it
+        for i in range(300):
+            c = rng.uniform(-8, 8, 3) + np.array([0, 0, 12])
+            if i % 4 == 0:
+                s.add_triangle(tuple(c), tuple(c + rng.uniform(-1, 1, 3)), tuple(c + rng.uniform(-1, 1, 3)),
+                               mats[i % 6])
+            else:
+                s.add_sphere(tuple(c), float(rng.uniform(0.2, 0.8)), mats[i % 6])
+        s.add_sphere((float("inf"), 0, 5), 1.0, mats[2])    # no finite box
+        s.add_sphere((1, 2, 9), float("nan"), mats[3])
+        s.add_triangle((0, 0, 1e38), (1e38, 0, 1e38), (0, 3e38, 1e38), mats[4])
+        ref, _ = oracle.render_rows(s, 90, 60, spp=3, max_bounces=4, seed=12)
+        for flags in (0x400, 0x420 & ~0x400 | 0x20, 0x10, 0x500):
+            got = gpu.render_frame(s, 90, 60, spp=3, max_bounces=4, seed=12, flags=flags)
+            assert np.array_equal(got, ref), hex(flags)
 
 
 def _bmp_pixels(path, w, h):
@@ -479,6 +550,8 @@ def test_randomised_scenes_match_the_oracle(gpu, oracle, branching):
             spp = int(rng.integers(1, 5))
             b = int(rng.integers(0, 11 if not branching else 5))
             flags = int(rng.choice([0, 0x40, 0x100, 0x20, 0x10, 0x140])) if not branching else int(rng.choice([0, 0x40]))
+            if not branching and s.num_objects >= 64 and trial % 2:
+                flags |= 0x400                           # hierarchy scan
             got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=trial, flags=flags)
             ref, _ = oracle.render_rows(s, w, h, spp=spp, max_bounces=b, seed=trial)
             assert np.array_equal(got, ref), (trial, w, h, spp, b, hex(flags), s.counts())
