@@ -1,8 +1,10 @@
+"""Kernel-time sweeps over scheduling knobs (run on the GPU box):
+    python tools/sweep_settle.py        # settle_lanes x scene storage, 4 scenes
+Also provides run(), used by tools/stamps.py and tools/bvh_scaling.py."""
 import sys
 sys.path.insert(0, '.')
 import torch
 import path_tracer_c_amd as pt
-from tools import sweep
 
 def run(cfgname, w=None, h=None, spp=None, flags=0, block=0, settle=0, reps=3):
     c = dict(pt.CONFIGS[int(cfgname[1])]) if cfgname != 'c0' else dict(scene=0, width=1280, height=800, spp=64, max_bounces=4, seed=1)
