@@ -18,7 +18,8 @@ def built():
     """Build the product library and the oracle once per session."""
     lib = ROOT / "path_tracer_c_amd" / "lib" / "libptgpu.so"
     ora = ROOT / "oracle" / "liboracle.so"
-    if not lib.exists() or not ora.exists():
+    exe = ROOT / "bin" / "ptrender"
+    if not lib.exists() or not ora.exists() or not exe.exists():
         import __graft_entry__
         __graft_entry__.build()
     return True
