@@ -159,18 +159,22 @@ def test_triangle_only_scene(gpu, oracle):
     assert np.array_equal(got, ref) and got.std() > 0
 
 
-def test_scene_larger_than_lds_falls_back_to_global_scan(gpu, oracle, flags=0x40):
+@pytest.mark.parametrize("n_spheres,what", [(4000, "LDS copy above the 64 KiB default limit"),
+                                            (9000, "too big for 160 KiB: global scan instead")])
+def test_large_scenes_with_the_lds_copy_requested(gpu, oracle, n_spheres, what):
     rng = np.random.default_rng(1)
     with gpu.HostScene() as s:
         s.set_sky(0.5, 0.6, 0.7)
         mats = [s.add_material(tuple(rng.uniform(0.2, 0.9, 3)), roughness=float(rng.uniform(0, 1)))
                 for _ in range(8)]
-        for _ in range(9000):                      # 9000 * 20 B > 160 KiB of LDS
+        for _ in range(n_spheres):
             c = (rng.uniform(-30, 30), rng.uniform(-10, 10), rng.uniform(5, 80))
             s.add_sphere(c, float(rng.uniform(0.1, 0.6)), mats[int(rng.integers(8))])
-        got = gpu.render_frame(s, 48, 27, spp=2, max_bounces=3, seed=4, flags=flags)
         ref, _ = oracle.render_rows(s, 48, 27, spp=2, max_bounces=3, seed=4)
-    assert np.array_equal(got, ref)
+        for flags in (0x40, 0x40 | 0x20, 0x40 | 0x100):        # bvh (default), screened, queue
+            got = gpu.render_frame(s, 48, 27, spp=2, max_bounces=3, seed=4, flags=flags,
+                                   block_threads=256)
+            assert np.array_equal(got, ref), (what, hex(flags))
 
 
 def test_branching_material_uses_the_tree_kernel(gpu, oracle):
