@@ -636,6 +636,42 @@ def test_render_task_called_directly_renders_one_row(gpu, oracle):
     assert np.array_equal(frame[7], ref[7]) and not frame[:7].any() and not frame[8:].any()
 
 
+def test_threadpool_two_frames_two_scenes_and_foreign_tasks_in_one_wait(gpu, oracle, monkeypatch):
+    """Rows of different frames / sizes / scenes queued together with ordinary
+    tasks: one wait finishes all of them; tasks dropped by destroy never run."""
+    monkeypatch.setenv("PTGPU_SPP", "4")
+    A = gpu._abi
+    lib = gpu.lib()
+    ran = []
+    cb = A.TASK_FN(lambda arg: ran.append(arg))
+    task = C.cast(lib.render_task, C.c_void_p)
+    with gpu.HostScene(1) as s1, gpu.HostScene(0) as s0:
+        f1 = np.zeros((40, 64, 3), dtype=np.uint8)
+        f0 = np.zeros((30, 48, 3), dtype=np.uint8)
+        jobs = [(s1, f1, 64, 40, y) for y in range(40)] + [(s0, f0, 48, 30, y) for y in range(0, 30, 2)]
+        args = (A.RenderArgs * len(jobs))()
+        pool = A.ThreadPool()
+        lib.threadpool_init(C.byref(pool), 2)
+        order = np.random.default_rng(0).permutation(len(jobs))
+        for n, k in enumerate(order):
+            sc, fr, w, h, y = jobs[k]
+            args[k] = A.RenderArgs(y, w, h, fr.ctypes.data_as(C.POINTER(C.c_uint8)), C.pointer(sc.c))
+            lib.threadpool_add_task(C.byref(pool), task, C.cast(C.byref(args[k]), C.c_void_p))
+            if n % 9 == 0:
+                lib.threadpool_add_task(C.byref(pool), C.cast(cb, C.c_void_p), C.c_void_p(1000 + n))
+        lib.threadpool_wait_for_tasks(C.byref(pool))
+        assert len(ran) == len(range(0, len(jobs), 9)) and pool.tasks.size == 0
+        r1, _ = oracle.render_rows(s1, 64, 40, spp=4, seed=1)
+        r0, _ = oracle.render_rows(s0, 48, 30, spp=4, seed=1)
+        assert np.array_equal(f1, r1)
+        assert np.array_equal(f0[0::2], r0[0::2]) and not f0[1::2].any()
+        # queued but never waited for: destroy drops them (src/threadpool.c:70-74)
+        before = len(ran)
+        lib.threadpool_add_task(C.byref(pool), C.cast(cb, C.c_void_p), C.c_void_p(7))
+        lib.threadpool_destroy(C.byref(pool))
+        assert len(ran) == before
+
+
 def test_threadpool_runs_foreign_tasks_and_waits_for_all(gpu):
     A = gpu._abi
     lib = gpu.lib()
