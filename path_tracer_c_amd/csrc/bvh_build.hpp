@@ -7,12 +7,15 @@
 // exact tests and the accept rule are the reference's, so the image does not
 // change.
 //
-// Layout: nodes in depth-first order, 32 bytes each,
-//     lo.xyz, skip   |   hi.xyz, leaf
-// `skip` = index of the first node after this node's subtree (where a ray
-// that misses the box continues); the left child of an inner node is the next
-// node.  `leaf` = 0 for an inner node, else (count << 24) | first, a run of
-// `count` (1..kLeafMax) entries of `order[]`, which holds object indices.
+// Layout: inner nodes only, 64 bytes each, each holding the boxes of its two
+// children (so one fetch decides both, and the nearer child can be entered
+// first):
+//     L.lo.xyz, L.ref | L.hi.xyz, - | R.lo.xyz, R.ref | R.hi.xyz, -
+// A ref is either an inner-node index (bit 31 clear) or a leaf:
+// 0x80000000 | count << 28 | first, a run of `count` (1..kLeafMax) entries of
+// `order[]`, which holds object indices.  `root` is the ref to start from
+// (a leaf when the whole scene fits one), `depth` the deepest chain of inner
+// nodes (= entries the traversal stack needs, at most).
 // Boxes are those of the objects' bounding spheres, inflated (relative 1e-3
 // plus an absolute term), so a ray the exact test can hit always crosses the
 // box.  Objects without a finite box (NaN / infinite coordinates or radius)
@@ -32,10 +35,14 @@ namespace pt {
 
 constexpr uint32_t kLeafMax = 4;
 
+constexpr uint32_t kBvhLeafBit = 0x80000000u;
+
 struct BvhHost {
-    std::vector<F4> nodes;           // 2 records per node
+    std::vector<F4> nodes;           // 4 records per inner node
     std::vector<uint32_t> order;     // object indices, leaf runs
     std::vector<uint32_t> unbounded; // objects tested for every ray
+    uint32_t root = kBvhLeafBit;     // empty leaf: nothing to visit
+    uint32_t depth = 0;
 };
 
 namespace bvh_detail {
@@ -55,54 +62,69 @@ struct Builder {
     std::vector<uint32_t> &items; // indices into boxes, permuted in place
     BvhHost &out;
 
-    // emits the subtree over items[begin, end) and returns its node index
-    uint32_t build(uint32_t begin, uint32_t end) {
-        const uint32_t me = (uint32_t)(out.nodes.size() / 2);
-        out.nodes.push_back(F4{0, 0, 0, 0});
-        out.nodes.push_back(F4{0, 0, 0, 0});
-        Box all, cent;
+    Box bounds(uint32_t begin, uint32_t end) const {
+        Box all;
         for (int a = 0; a < 3; ++a) {
-            all.lo[a] = cent.lo[a] = std::numeric_limits<float>::infinity();
-            all.hi[a] = cent.hi[a] = -std::numeric_limits<float>::infinity();
+            all.lo[a] = std::numeric_limits<float>::infinity();
+            all.hi[a] = -std::numeric_limits<float>::infinity();
         }
         for (uint32_t k = begin; k < end; ++k) {
             const Box &b = boxes[items[k]];
             for (int a = 0; a < 3; ++a) {
                 all.lo[a] = std::min(all.lo[a], b.lo[a]);
                 all.hi[a] = std::max(all.hi[a], b.hi[a]);
-                const float c = 0.5f * b.lo[a] + 0.5f * b.hi[a];
-                cent.lo[a] = std::min(cent.lo[a], c);
-                cent.hi[a] = std::max(cent.hi[a], c);
             }
         }
-        uint32_t leaf = 0;
+        return all;
+    }
+
+    // emits the subtree over items[begin, end); returns its ref and box
+    uint32_t build(uint32_t begin, uint32_t end, uint32_t level, Box &box) {
+        box = bounds(begin, end);
         const uint32_t n = end - begin;
-        int axis = 0;
-        for (int a = 1; a < 3; ++a)
-            if (cent.hi[a] - cent.lo[a] > cent.hi[axis] - cent.lo[axis])
-                axis = a;
-        const bool splittable = cent.hi[axis] > cent.lo[axis];
         if (n <= kLeafMax) {
-            leaf = (n << 24) | (uint32_t)out.order.size();
+            const uint32_t ref = kBvhLeafBit | (n << 28) | (uint32_t)out.order.size();
             for (uint32_t k = begin; k < end; ++k)
                 out.order.push_back(items[k]);
-        } else {
-            // (objects sharing one centre cannot be split spatially: they are
-            // halved by index instead, so leaves never exceed kLeafMax)
-            const uint32_t mid = begin + n / 2;
-            if (splittable)
-                std::nth_element(items.begin() + begin, items.begin() + mid,
-                                 items.begin() + end, [&](uint32_t x, uint32_t y) {
-                                     const float cx = boxes[x].lo[axis] + boxes[x].hi[axis];
-                                     const float cy = boxes[y].lo[axis] + boxes[y].hi[axis];
-                                     return cx < cy;
-                                 });
-            build(begin, mid); // left child = me + 1
-            build(mid, end);
+            return ref;
         }
-        const uint32_t skip = (uint32_t)(out.nodes.size() / 2);
-        out.nodes[2 * me + 0] = F4{all.lo[0], all.lo[1], all.lo[2], as_float(skip)};
-        out.nodes[2 * me + 1] = F4{all.hi[0], all.hi[1], all.hi[2], as_float(leaf)};
+        out.depth = std::max(out.depth, level + 1);
+        // split at the median of the centres along their widest axis (objects
+        // sharing one centre cannot be split spatially: halved by index)
+        float clo[3], chi[3];
+        for (int a = 0; a < 3; ++a) {
+            clo[a] = std::numeric_limits<float>::infinity();
+            chi[a] = -std::numeric_limits<float>::infinity();
+        }
+        for (uint32_t k = begin; k < end; ++k) {
+            const Box &b = boxes[items[k]];
+            for (int a = 0; a < 3; ++a) {
+                const float c = 0.5f * b.lo[a] + 0.5f * b.hi[a];
+                clo[a] = std::min(clo[a], c);
+                chi[a] = std::max(chi[a], c);
+            }
+        }
+        int axis = 0;
+        for (int a = 1; a < 3; ++a)
+            if (chi[a] - clo[a] > chi[axis] - clo[axis])
+                axis = a;
+        const uint32_t mid = begin + n / 2;
+        if (chi[axis] > clo[axis])
+            std::nth_element(items.begin() + begin, items.begin() + mid,
+                             items.begin() + end, [&](uint32_t x, uint32_t y) {
+                                 const float cx = boxes[x].lo[axis] + boxes[x].hi[axis];
+                                 const float cy = boxes[y].lo[axis] + boxes[y].hi[axis];
+                                 return cx < cy;
+                             });
+        const uint32_t me = (uint32_t)(out.nodes.size() / 4);
+        out.nodes.resize(out.nodes.size() + 4);
+        Box lbox, rbox;
+        const uint32_t lref = build(begin, mid, level + 1, lbox);
+        const uint32_t rref = build(mid, end, level + 1, rbox);
+        out.nodes[4 * me + 0] = F4{lbox.lo[0], lbox.lo[1], lbox.lo[2], as_float(lref)};
+        out.nodes[4 * me + 1] = F4{lbox.hi[0], lbox.hi[1], lbox.hi[2], 0.0f};
+        out.nodes[4 * me + 2] = F4{rbox.lo[0], rbox.lo[1], rbox.lo[2], as_float(rref)};
+        out.nodes[4 * me + 3] = F4{rbox.hi[0], rbox.hi[1], rbox.hi[2], 0.0f};
         return me;
     }
 };
@@ -140,7 +162,8 @@ inline BvhHost build_bvh(const F4 *geom, uint32_t n_obj) {
     }
     if (!items.empty()) {
         bvh_detail::Builder builder{boxes, items, out};
-        builder.build(0, (uint32_t)items.size());
+        Box all;
+        out.root = builder.build(0, (uint32_t)items.size(), 0, all);
         for (uint32_t &o : out.order) // box index -> object index
             o = box_owner[o];
     }

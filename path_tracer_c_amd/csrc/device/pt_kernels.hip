@@ -476,6 +476,7 @@ stage_scene(const LaunchArgs &a, uint4 *lds_dyn, uint32_t tid, uint32_t nthreads
     w.rec.bvh_unbounded = a.scene.bvh_unbounded;
     w.rec.n_nodes = a.scene.n_nodes;
     w.rec.n_unbounded = a.scene.n_unbounded;
+    w.rec.bvh_root = a.scene.bvh_root;
     w.stack = reinterpret_cast<uint16_t *>(lds_dyn + lds_used16) + tid;
     // the candidate queues of the screened scan sit behind the bounce stack
     // (2 * nthreads * (max_bounces + 1) bytes, rounded up to 16)
@@ -483,6 +484,8 @@ stage_scene(const LaunchArgs &a, uint4 *lds_dyn, uint32_t tid, uint32_t nthreads
     w.queue.slot =
         reinterpret_cast<uint32_t *>(lds_dyn + lds_used16 + stack16) + tid;
     w.queue.stride = nthreads;
+    // and behind them the traversal stacks of the BVH scan
+    w.queue.stack = w.queue.slot + kScreenQueue * nthreads;
     __syncthreads();
     return w;
 }
@@ -848,9 +851,11 @@ __global__ void __launch_bounds__(256)
     rec.bvh_unbounded = scene.bvh_unbounded;
     rec.n_nodes = scene.n_nodes;
     rec.n_unbounded = scene.n_unbounded;
+    rec.bvh_root = scene.bvh_root;
     ScreenQueue queue;
     queue.slot = reinterpret_cast<uint32_t *>(lds_dyn) + threadIdx.x;
     queue.stride = blockDim.x;
+    queue.stack = queue.slot + kScreenQueue * blockDim.x;
     const V3 o = V3{origins[3 * at], origins[3 * at + 1], origins[3 * at + 2]};
     const V3 d = V3{directions[3 * at], directions[3 * at + 1],
                     directions[3 * at + 2]};
@@ -902,6 +907,8 @@ size_t megakernel_lds_bytes(const LaunchArgs &a, uint32_t block, bool tree) {
         bytes += ((size_t)2 * block * ((size_t)a.max_bounces + 1u) + 15u) & ~(size_t)15u;
         if (a.screened)
             bytes += (size_t)4 * block * kScreenQueue;
+        if (a.screened == 2u)
+            bytes += (size_t)4 * block * (a.scene.bvh_depth + 2u);
     }
     return (bytes + 15u) & ~(size_t)15u;
 }
@@ -1013,7 +1020,7 @@ hipError_t launch_trace(const SceneDesc &scene, const float *origins,
     if (n == 0)
         return hipSuccess;
     const uint32_t grid = (uint32_t)((n + 255u) / 256u);
-    const size_t lds = (size_t)4 * 256u * kScreenQueue;
+    const size_t lds = (size_t)4 * 256u * (kScreenQueue + scene.bvh_depth + 2u);
     if (scan == 2)
         hipLaunchKernelGGL(pt_trace_kernel<2>, dim3(grid), dim3(256), lds, stream,
                            scene, origins, directions, n, hits);

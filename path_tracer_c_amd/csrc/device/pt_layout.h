@@ -51,11 +51,13 @@ struct SceneDesc {
     const uint32_t *link; // n_obj
     // optional hierarchy over the objects (csrc/bvh_build.hpp); n_nodes == 0
     // when it was not built
-    const F4 *bvh_nodes;           // 2 * n_nodes
+    const F4 *bvh_nodes;           // 4 * n_nodes (inner nodes, child boxes inside)
     const uint32_t *bvh_order;     // object indices, leaf runs
     const uint32_t *bvh_unbounded; // objects without a finite box
     uint32_t n_nodes;
     uint32_t n_unbounded;
+    uint32_t bvh_root;             // ref to start from (leaf bit = 0x80000000)
+    uint32_t bvh_depth;            // deepest chain of inner nodes
     uint32_t n_obj;
     uint32_t n_tri;
     uint32_t n_mat;

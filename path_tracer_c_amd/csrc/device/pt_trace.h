@@ -33,6 +33,7 @@ struct SceneRecords {
     const uint32_t *bvh_unbounded;
     uint32_t n_nodes;
     uint32_t n_unbounded;
+    uint32_t bvh_root;
 };
 
 PT_HD V3 xyz(const F4 &r) { return V3{r.x, r.y, r.z}; }
@@ -149,10 +150,12 @@ PT_HD Hit closest_hit(const SceneRecords &rec, V3 o, V3 d) {
 //            per wave.
 constexpr uint32_t kScreenBlock = 8;
 constexpr uint32_t kScreenQueue = 12; // >= kScreenBlock + 1
+constexpr uint32_t kLeafRef = 0x80000000u; // BVH refs: bit 31 = leaf (csrc/bvh_build.hpp)
 
 struct ScreenQueue {
     uint32_t *slot;   // this lane's entry 0 in LDS
     uint32_t stride;  // entries of one lane are `stride` words apart
+    uint32_t *stack;  // BVH scan: this lane's traversal stack, same stride
 };
 
 __device__ __forceinline__ bool screen_keep(const F4 g, V3 o, V3 d) {
@@ -235,15 +238,18 @@ __device__ __forceinline__ Hit closest_hit_screened(const SceneRecords &rec,
 // the answer; if L is the last object, L is; otherwise (rare) the lane walks
 // the hierarchy once more, considering only indices > L.
 //
-// Traversal is stackless (depth-first node order + skip links), one node per
-// lane per pass of the loop; a box test is a slab test with slack
-// proportional to the distances involved (the exact tests are themselves
-// only accurate to ~|c-o| * 2^-23, so a far-away ray must be allowed to "hit"
-// generously), and nodes wholly beyond the best exact distance so far are
-// skipped.  Leaf objects go through the conservative sphere screen into the
-// lane's LDS queue; exact tests run in dense resolve phases, as in the
-// screened scan.  Triangles can never be degenerate (their test demands
-// distance > 1e-6).
+// Traversal: one inner node per lane per pass of the loop.  A node carries
+// the boxes of both children, so one 64-byte fetch decides both; if the ray
+// crosses both, the nearer one is entered and the other goes on the lane's
+// stack in LDS (depth = tree depth, known at upload).  A box test is a slab
+// test with slack proportional to the distances involved (the exact tests
+// are themselves only accurate to ~|c-o| * 2^-23, so a far-away ray must be
+// allowed to "hit" generously), written as "not certainly missed" so that a
+// NaN can only widen the search; children wholly beyond the best exact
+// distance so far are not entered.  Leaf objects go through the conservative
+// sphere screen into the lane's LDS queue; exact tests run in dense resolve
+// phases, as in the screened scan, early enough that `best` is known soon.
+// Triangles can never be degenerate (their test demands distance > 1e-6).
 // ---------------------------------------------------------------------------
 struct UnorderedBest {
     float best;     // smallest positive distance so far
@@ -323,7 +329,22 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
 
     const V3 inv = V3{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y),
                       __builtin_amdgcn_rcpf(d.z)};
-    const uint32_t n = rec.n_nodes;
+    // slab test of one box: false only if the ray certainly misses it or the
+    // box lies wholly beyond `u.best`
+    auto crosses = [&](const F4 lo, const F4 hi, float &enter) {
+        const float x0 = (lo.x - o.x) * inv.x, x1 = (hi.x - o.x) * inv.x;
+        const float y0 = (lo.y - o.y) * inv.y, y1 = (hi.y - o.y) * inv.y;
+        const float z0 = (lo.z - o.z) * inv.z, z1 = (hi.z - o.z) * inv.z;
+        // fminf/fmaxf drop a NaN operand (0 * inf on a box face)
+        enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+        const float leave = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        const float slack = 1.0e-4f * (fabsf(enter) + fabsf(leave));
+        const bool missed = (enter == __builtin_inff()) | (leave == -__builtin_inff()) |
+                            (leave - enter < -slack) | (leave < -slack) |
+                            (enter - slack > u.best);
+        return !missed;
+    };
+    constexpr uint32_t kDone = 0xFFFFFFFFu; // not a valid ref: count field would be 7
     for (int walk = 0; walk < 2; ++walk) {
         if (!__any(walking))
             break;
@@ -336,43 +357,54 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
             if (__any(wr > nearly_full))
                 resolve();
         }
-        uint32_t node = walking ? 0u : n;
-        while (__any(node < n)) {
-            if (node < n) {
-                const F4 lo = rec.bvh_nodes[2u * node + 0u];
-                const F4 hi = rec.bvh_nodes[2u * node + 1u];
-                const float x0 = (lo.x - o.x) * inv.x, x1 = (hi.x - o.x) * inv.x;
-                const float y0 = (lo.y - o.y) * inv.y, y1 = (hi.y - o.y) * inv.y;
-                const float z0 = (lo.z - o.z) * inv.z, z1 = (hi.z - o.z) * inv.z;
-                // fminf/fmaxf drop a NaN operand (0 * inf on a box face)
-                const float enter =
-                    fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-                const float leave =
-                    fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-                const float slack = 1.0e-4f * (fabsf(enter) + fabsf(leave));
-                // written as "not certainly missed": every comparison is false
-                // for a NaN, so a ray with NaN components (they occur: a 0/0
-                // root makes the next ray NaN, and the sequential walk then
-                // "hits" every sphere) visits everything, as it must
-                const bool missed = (enter == __builtin_inff()) |
-                                    (leave == -__builtin_inff()) |
-                                    (leave - enter < -slack) | (leave < -slack) |
-                                    (enter - slack > u.best);
-                const bool crossed = !missed;
-                const uint32_t skip = __builtin_bit_cast(uint32_t, lo.w);
-                const uint32_t leaf = __builtin_bit_cast(uint32_t, hi.w);
-                if (crossed && leaf != 0u) {
-                    const uint32_t count = leaf >> 24;
-                    const uint32_t at = leaf & 0x00FFFFFFu;
-                    for (uint32_t k = 0; k < count; ++k) {
-                        const uint32_t idx = rec.bvh_order[at + k];
-                        if (idx >= min_index && screen_keep(rec.geom[idx], o, d)) {
-                            *wr = idx;
-                            wr += q.stride;
-                        }
+        uint32_t cur = walking ? rec.bvh_root : kDone;
+        uint32_t *sp = q.stack; // next free stack entry of this lane
+        while (__any(cur != kDone)) {
+            // descend until no lane of the wave stands on an inner node: the
+            // leaf code below then runs once for many lanes instead of on
+            // every pass for a few
+            while (__any(cur != kDone && !(cur & kLeafRef))) {
+                if (cur != kDone && !(cur & kLeafRef)) {
+                    const F4 l_lo = rec.bvh_nodes[4u * cur + 0u];
+                    const F4 l_hi = rec.bvh_nodes[4u * cur + 1u];
+                    const F4 r_lo = rec.bvh_nodes[4u * cur + 2u];
+                    const F4 r_hi = rec.bvh_nodes[4u * cur + 3u];
+                    float l_enter, r_enter;
+                    const bool go_l = crosses(l_lo, l_hi, l_enter);
+                    const bool go_r = crosses(r_lo, r_hi, r_enter);
+                    const uint32_t l_ref = __builtin_bit_cast(uint32_t, l_lo.w);
+                    const uint32_t r_ref = __builtin_bit_cast(uint32_t, r_lo.w);
+                    if (go_l & go_r) {
+                        const bool r_first = r_enter < l_enter;
+                        *sp = r_first ? l_ref : r_ref; // the farther child waits
+                        sp += q.stride;
+                        cur = r_first ? r_ref : l_ref;
+                    } else if (go_l | go_r) {
+                        cur = go_l ? l_ref : r_ref;
+                    } else if (sp != q.stack) {
+                        sp -= q.stride;
+                        cur = *sp;
+                    } else {
+                        cur = kDone;
                     }
                 }
-                node = crossed ? node + 1u : skip; // a leaf's skip link is node + 1
+            }
+            if (cur != kDone) { // a leaf
+                const uint32_t count = (cur >> 28) & 7u;
+                const uint32_t at = cur & 0x0FFFFFFFu;
+                for (uint32_t k = 0; k < count; ++k) {
+                    const uint32_t idx = rec.bvh_order[at + k];
+                    if (idx >= min_index && screen_keep(rec.geom[idx], o, d)) {
+                        *wr = idx;
+                        wr += q.stride;
+                    }
+                }
+                if (sp != q.stack) {
+                    sp -= q.stride;
+                    cur = *sp;
+                } else {
+                    cur = kDone;
+                }
             }
             if (__any(wr > nearly_full))
                 resolve();

@@ -338,6 +338,8 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
     h->desc.bvh_unbounded = nullptr;
     h->desc.n_nodes = 0;
     h->desc.n_unbounded = 0;
+    h->desc.bvh_root = pt::kBvhLeafBit;
+    h->desc.bvh_depth = 0;
     if (n_obj >= kBvhMinObjects) {
         const pt::BvhHost bvh = pt::build_bvh(geom, n_obj);
         const size_t node_bytes = bvh.nodes.size() * sizeof(pt::F4);
@@ -362,8 +364,10 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
         h->desc.bvh_nodes = reinterpret_cast<const pt::F4 *>(b0);
         h->desc.bvh_order = reinterpret_cast<const uint32_t *>(b0 + node_bytes);
         h->desc.bvh_unbounded = reinterpret_cast<const uint32_t *>(b0 + node_bytes + order_bytes);
-        h->desc.n_nodes = (uint32_t)(bvh.nodes.size() / 2);
+        h->desc.n_nodes = (uint32_t)(bvh.nodes.size() / 4);
         h->desc.n_unbounded = (uint32_t)bvh.unbounded.size();
+        h->desc.bvh_root = bvh.root;
+        h->desc.bvh_depth = bvh.depth;
     }
     h->desc.n_obj = n_obj;
     h->desc.n_tri = n_tri;
