@@ -1,35 +1,38 @@
-// pt_kernels.hip -- the gfx950 megakernel of the render path.
+// pt_kernels.hip -- the gfx950 kernels of the render path.
 //
-// One work-item per pixel of the call's row set.  A work-item owns its pixel
-// for the whole launch: it generates the primary ray once (the reference
-// sends the same un-jittered ray for every sample, src/renderer.c:96-100),
-// then runs all `spp` samples of src/renderer.c:103-107 -- each the
-// recursive incident_light of src/renderer.c:21-74 -- adds the clamped
-// samples in sample order, scales, truncates and stores RGB8
-// (src/renderer.c:108-114).  One launch replaces the whole
-// threadpool_add_task/render_task/threadpool_wait_for_tasks frame loop.
+// What they compute is the reference's render_task (src/renderer.c:92-116)
+// for every pixel of a call's row set: the primary ray of src/renderer.c:76-85
+// (the same un-jittered ray for every sample of a pixel), `spp` samples of the
+// recursive incident_light (src/renderer.c:21-74) over trace_ray
+// (src/ray.c:4-73), each clamped, summed in sample order, scaled, truncated
+// and stored as RGB8 (src/renderer.c:88,103-114).  One call replaces the
+// whole threadpool_add_task / render_task / threadpool_wait_for_tasks loop.
 //
-// Shape of the computation on a CU:
-//   * the scene blob (geometry, triangle records, materials, meta) is copied
-//     once per workgroup into LDS; the object scan then reads it with
-//     wave-uniform (broadcast) LDS reads.  Variant: scan it from global
-//     memory (scalar/L2-served loads) for scenes that do not fit LDS and for
-//     the LDS-vs-global comparison of configuration 5.
-//   * incident_light's recursion is unrolled into a forward walk that records
-//     one 16-bit material index per bounce in an LDS stack, and an unwind that
-//     re-applies `Le + lerp(refl, trans, t) * albedo` from the deepest level
-//     up -- the reference's own evaluation order, so results are bit-equal to
-//     a sequential evaluation, which a throughput-product formulation is not.
-//   * path regeneration: a lane whose path ends starts its next sample at
-//     once, so lanes of a wave do not wait for the longest path of each
-//     sample; a wave leaves the loop when its busiest lane is done.  The
-//     ballot of finished lanes is only used for statistics here.
+//   pt_megakernel     pixel-owner schedule: one work-item per pixel, all its
+//                     samples, one launch per frame
+//   pt_samplekernel   sample-queue schedule: persistent waves pull
+//   + pt_sum_kernel   (pixel, sample) paths from a queue; the ordered
+//                     per-pixel sum runs afterwards (same bits)
+//   pt_resolve_kernel float4 accumulator -> RGB8
+//   pt_trace_kernel   batched trace_ray
+//
+// Common building blocks:
+//   * the scene records are scanned with wave-uniform scalar loads (default)
+//     or from a per-workgroup LDS copy; three scan forms (plain, screened,
+//     BVH) in pt_trace.h;
+//   * incident_light's recursion is a forward walk that records one 16-bit
+//     material index per bounce in an LDS stack, and an unwind that re-applies
+//     `Le + lerp(refl, trans, t) * albedo` from the deepest level up -- the
+//     reference's own evaluation order, so results are bit-equal to a
+//     sequential evaluation, which a throughput-product formulation is not;
+//   * lanes whose path ended park, and settle (unwind, emit, take new work)
+//     together when the wave's ballots say enough of them are waiting;
 //   * per-lane xorshift32 in a register, re-seeded per (pixel, sample)
 //     (include/ptgpu_rng.h), three draws per hit like rand_unit_sphere
-//     (src/renderer.c:11-19).
+//     (src/renderer.c:11-19);
 //   * materials with 0 < transparency < 1 make incident_light a binary tree
 //     (src/renderer.c:45,56,72); scenes that have one run the `kTree`
-//     instantiation, an explicit depth-first walk with a per-lane frame stack.
+//     instantiation, an explicit depth-first walk with a per-lane frame stack;
 //   * RGB8 stores: a wave's 64 pixels are 192 contiguous bytes; lanes 0..47
 //     each assemble one dword with two cross-lane reads and store it.
 //

@@ -35,7 +35,6 @@
 
 namespace pt {
 
-constexpr uint32_t kMetaTriangle = 0x80000000u;
 constexpr uint32_t kMetaMaterialMask = 0x7FFFFFFFu;
 
 struct F4 { // plain 16-byte record usable on host and device
