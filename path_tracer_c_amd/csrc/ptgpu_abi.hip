@@ -423,8 +423,8 @@ uint32_t auto_settle_lanes(const pt::SceneDesc &d) {
     return (uint32_t)(f + 0.5);
 }
 
-// Validates a call and fills the launch block.  `dest_rows` is the number of
-// rows the destination buffer must hold.
+// Validates a call and fills the launch block (everything but the
+// destination pointers).
 int prepare_launch(const ptgpu_scene *s, size_t framew, size_t frameh,
                    const ptgpu_params *p, pt::LaunchArgs *a, uint32_t *block,
                    bool *tree) {
@@ -573,6 +573,7 @@ int scratch_for_current_device(DeviceScratch **out) {
     if (rc != PTGPU_OK)
         return rc;
     DeviceScratch &sc = g_scratch[dev];
+    std::lock_guard<std::mutex> guard(g_ctx_mutex);
     if (sc.chunk_counters == nullptr) {
         PT_TRY_HIP(hipMalloc(&sc.chunk_counters, kCounterRing * sizeof(uint32_t)));
         PT_TRY_HIP(hipEventCreateWithFlags(&sc.last_use, hipEventDisableTiming));
@@ -616,9 +617,10 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
     if (mode < 0 && !can_measure)
         mode = kPixelOwner;
 
-    if (mode == kPixelOwner && d_frame != nullptr) { // the one-launch fast path
-        a.frame = d_frame;
-        a.accum = nullptr;
+    if (mode == kPixelOwner) { // the one-launch fast path, no scratch involved
+        a.frame = d_frame;  // exactly one of the two is non-null
+        a.accum = d_accum;
+        a.accum_local = 0;
         hipError_t e = pt::launch_megakernel(a, block, tree, stream);
         if (e != hipSuccess)
             return fail_hip(e, "megakernel launch");
