@@ -124,6 +124,7 @@ __device__ __forceinline__ V3 shade_level(const F4 m0, const F4 m1, V3 child) {
 // The host picks settle_lanes from the scene size (a pass over 1000 objects
 // dwarfs a settle; a pass over 8 does not).  The image does not depend on it.
 // ---------------------------------------------------------------------------
+
 // Diagnostic build only (make EXTRA_HIPFLAGS=-DPT_STAMPS): wave-level cycle
 // shares of the scene scan, the shading and the settle stage, summed into
 // three device words that no kernel reads and no output depends on
@@ -154,9 +155,6 @@ struct PathState {
     bool parked;    // path ended, waiting for the settle stage
 };
 
-// One recursion level of incident_light for a live lane: scan the scene, then
-// either end the path (miss, depth limit, total internal reflection) or
-// produce the next ray (src/renderer.c:24-70).
 // kScan: 0 plain linear scan, 1 screened linear scan, 2 BVH scan.
 template <int kScan>
 __device__ __forceinline__ Hit scan_scene(const SceneRecords &rec, V3 o, V3 d,
@@ -168,6 +166,9 @@ __device__ __forceinline__ Hit scan_scene(const SceneRecords &rec, V3 o, V3 d,
     return closest_hit(rec, o, d);
 }
 
+// One recursion level of incident_light for a live lane: scan the scene, then
+// either end the path (miss, depth limit, total internal reflection) or
+// produce the next ray (src/renderer.c:24-70).
 // `known` (wave-uniform): the closest hit of p's ray is already in `h_known`.
 template <int kScan>
 __device__ __forceinline__ void
@@ -278,7 +279,7 @@ run_paths(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
             if (!all_at_start)
                 ++scans;
             advance_path<kScan>(rec, a, stack, stack_stride, queue, sky, p,
-                                  all_at_start, h_primary);
+                                all_at_start, h_primary);
         }
         PT_STAMP(settle0);
         if (settle_now(p.live, p.parked, a.settle_lanes)) {
