@@ -565,6 +565,7 @@ __device__ __forceinline__ void count_wave(Counters *c, uint32_t rays,
                                            uint32_t iters, uint32_t lane) {
     if (c == nullptr)
         return;
+    c += blockIdx.x & (kCounterShards - 1u);
     const uint32_t wrays = wave_sum(rays);
     const uint32_t wscans = wave_sum(scans);
     const uint32_t wsamples = wave_sum(samples);

@@ -85,11 +85,26 @@ int counters_for_current_device(pt::Counters **out) {
     std::lock_guard<std::mutex> guard(g_ctx_mutex);
     if (g_counters[dev] == nullptr) {
         pt::Counters *c = nullptr;
-        PT_TRY_HIP(hipMalloc(&c, sizeof(pt::Counters)));
-        PT_TRY_HIP(hipMemset(c, 0, sizeof(pt::Counters)));
+        PT_TRY_HIP(hipMalloc(&c, sizeof(pt::Counters) * pt::kCounterShards));
+        PT_TRY_HIP(hipMemset(c, 0, sizeof(pt::Counters) * pt::kCounterShards));
         g_counters[dev] = c;
     }
     *out = g_counters[dev];
+    return PTGPU_OK;
+}
+
+// Sum of the counter shards (synchronous copy on the default stream).
+int read_counters(const pt::Counters *device, pt::Counters *total) {
+    std::vector<pt::Counters> shards(pt::kCounterShards);
+    PT_TRY_HIP(hipMemcpy(shards.data(), device, sizeof(pt::Counters) * pt::kCounterShards,
+                         hipMemcpyDeviceToHost));
+    std::memset(total, 0, sizeof *total);
+    for (const pt::Counters &c : shards) {
+        total->rays += c.rays;
+        total->samples += c.samples;
+        total->wave_iters += c.wave_iters;
+        total->scans += c.scans;
+    }
     return PTGPU_OK;
 }
 
@@ -670,7 +685,9 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         const uint32_t pilot = total_spp / 2 < 16u ? total_spp / 2 : 16u;
         pt::Counters before, after;
         PT_TRY_HIP(hipStreamSynchronize(stream));
-        PT_TRY_HIP(hipMemcpy(&before, a.counters, sizeof before, hipMemcpyDeviceToHost));
+        rc = read_counters(a.counters, &before);
+        if (rc != PTGPU_OK)
+            return rc;
         if (accum_is_zero) {
             PT_TRY_HIP(hipMemsetAsync(accum, 0, (size_t)npix * 16u, stream));
             accum_is_zero = false;
@@ -682,7 +699,9 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
             return fail_hip(e, "megakernel launch (pilot)");
         count_launch();
         PT_TRY_HIP(hipStreamSynchronize(stream));
-        PT_TRY_HIP(hipMemcpy(&after, a.counters, sizeof after, hipMemcpyDeviceToHost));
+        rc = read_counters(a.counters, &after);
+        if (rc != PTGPU_OK)
+            return rc;
         const double rays = (double)(after.rays - before.rays);
         const double samples = (double)(after.samples - before.samples);
         const double lane_passes = 64.0 * (double)(after.wave_iters - before.wave_iters);
@@ -1059,7 +1078,7 @@ int ptgpu_stats_reset(void) {
     if (rc != PTGPU_OK)
         return rc;
     PT_TRY_HIP(hipDeviceSynchronize());
-    PT_TRY_HIP(hipMemset(c, 0, sizeof *c));
+    PT_TRY_HIP(hipMemset(c, 0, sizeof(pt::Counters) * pt::kCounterShards));
     int dev = 0;
     if (current_device(&dev) == PTGPU_OK)
         g_launches[dev].store(0);
@@ -1075,7 +1094,9 @@ int ptgpu_stats_read(ptgpu_stats *out) {
         return rc;
     pt::Counters host;
     PT_TRY_HIP(hipDeviceSynchronize());
-    PT_TRY_HIP(hipMemcpy(&host, c, sizeof host, hipMemcpyDeviceToHost));
+    rc = read_counters(c, &host);
+    if (rc != PTGPU_OK)
+        return rc;
     out->rays = host.rays;
     out->samples = host.samples;
     out->wave_iters = host.wave_iters;
