@@ -306,10 +306,7 @@ def main():
                 "msample_per_s": samples / elapsed / 1e6,
                 "lane_utilisation": rays / (64.0 * wave_iters) if wave_iters else None,
                 "schedule": dscene.schedule,
-                "scan": ("plain" if n_sph + n_tri < 32 else
-                         "screened linear" if n_sph + n_tri < 768 else
-                         "bvh (roofline.achieved still prices a ray at the linear scan's "
-                         "algorithmic FLOP count, i.e. it is an effective rate)"),
+                "scan": dscene.scan,
             },
             "roofline": {
                 "kernel": "pt_samplekernel" if dscene.schedule == "sample-queue" else "pt_megakernel",

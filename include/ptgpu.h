@@ -64,10 +64,15 @@ extern "C" {
                                          if no material needs it */
 #define PTGPU_FLAG_NO_RAY_COUNT 0x8u  /* skip the ray/sample counters */
 #define PTGPU_FLAG_SCAN_PLAIN 0x10u   /* scheduling only: test every object in
-                                         full (default for < 32 objects) */
+                                         full */
 #define PTGPU_FLAG_SCAN_SCREENED 0x20u /* scheduling only: conservative screen
-                                         + per-lane queues (default for >= 32
-                                         objects); same image either way */
+                                         + per-lane queues.  Same image either
+                                         way.  Without a SCAN flag the form is
+                                         timed on a scene's first large render
+                                         (8 samples per candidate form) and
+                                         remembered; smaller renders go by
+                                         object count: plain < 32 <= screened
+                                         < 768 <= BVH */
 
 #define PTGPU_FLAG_PIXEL_OWNER 0x80u   /* scheduling only: one work-item owns a
                                          pixel for all its samples (one launch
@@ -161,6 +166,9 @@ int ptgpu_scene_is_branching(const ptgpu_scene *s);
 /* Schedule remembered for this scene: 0 not measured yet, 1 pixel-owner,
  * 2 sample-queue (see PTGPU_FLAG_PIXEL_OWNER / _SAMPLE_QUEUE). */
 int ptgpu_scene_schedule(const ptgpu_scene *s);
+/* Scan form remembered for this scene (measured on the same occasion):
+ * 0 not measured yet, 1 plain, 2 screened linear, 3 BVH. */
+int ptgpu_scene_scan(const ptgpu_scene *s);
 
 /* -- rendering ------------------------------------------------------------- */
 /* Asynchronous: renders the row set of `p` of a framew x frameh image into

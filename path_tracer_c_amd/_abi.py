@@ -195,6 +195,7 @@ SIGNATURES = {
     "ptgpu_scene_free": (None, [C.c_void_p]),
     "ptgpu_scene_is_branching": (C.c_int, [C.c_void_p]),
     "ptgpu_scene_schedule": (C.c_int, [C.c_void_p]),
+    "ptgpu_scene_scan": (C.c_int, [C.c_void_p]),
     "ptgpu_release_scratch": (C.c_int, []),
     "ptgpu_render_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t,
                                       C.c_size_t, C.POINTER(Params), C.c_void_p]),

