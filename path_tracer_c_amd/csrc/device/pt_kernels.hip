@@ -468,6 +468,13 @@ stage_scene(const LaunchArgs &a, uint4 *lds_dyn, uint32_t tid, uint32_t nthreads
                                                         2u * n_mat);
         w.rec.link = w.rec.meta + n_obj;
         lds_used16 = blob16;
+        if (a.screened == 2u) { // the hierarchy's nodes ride along
+            const uint32_t node16 = 4u * a.scene.n_nodes;
+            const uint4 *nsrc = reinterpret_cast<const uint4 *>(a.scene.bvh_nodes);
+            for (uint32_t i = tid; i < node16; i += nthreads)
+                lds_dyn[lds_used16 + i] = nsrc[i];
+            lds_used16 += node16;
+        }
     } else {
         w.rec.geom = a.scene.geom;
         w.rec.tri = a.scene.tri;
@@ -475,7 +482,10 @@ stage_scene(const LaunchArgs &a, uint4 *lds_dyn, uint32_t tid, uint32_t nthreads
         w.rec.meta = a.scene.meta;
         w.rec.link = a.scene.link;
     }
-    w.rec.bvh_nodes = a.scene.bvh_nodes;
+    w.rec.bvh_nodes = (kLds && a.screened == 2u)
+                          ? reinterpret_cast<const F4 *>(lds_dyn) +
+                                (scene_lds_bytes(n_obj, n_tri, n_mat) / 16u)
+                          : a.scene.bvh_nodes;
     w.rec.bvh_order = a.scene.bvh_order;
     w.rec.bvh_unbounded = a.scene.bvh_unbounded;
     w.rec.n_nodes = a.scene.n_nodes;
@@ -906,8 +916,11 @@ static hipError_t launch_variant(const LaunchArgs &a, uint32_t grid,
 
 size_t megakernel_lds_bytes(const LaunchArgs &a, uint32_t block, bool tree) {
     size_t bytes = 0;
-    if (a.scene_in_lds)
+    if (a.scene_in_lds) {
         bytes += scene_lds_bytes(a.scene.n_obj, a.scene.n_tri, a.scene.n_mat);
+        if (a.screened == 2u && !tree)
+            bytes += (size_t)64 * a.scene.n_nodes;
+    }
     if (!tree) {
         bytes += ((size_t)2 * block * ((size_t)a.max_bounces + 1u) + 15u) & ~(size_t)15u;
         if (a.screened)
