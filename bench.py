@@ -347,6 +347,18 @@ def main():
                 "scene_scans_per_s_M": s2.scans / 3 / ms / 1e3,
                 "scans_per_segment": s2.scans / s2.rays,
                 "note": "library default; same image; not used for `value`"}
+        if world == 1 and not progressive:
+            # end to end through the host-buffer entry point (PCIe included):
+            # scene upload + kernel + frame download; reported, never `value`
+            import numpy as _np
+            host = _np.zeros((h, w, 3), dtype=_np.uint8)
+            kw = dict(spp=cfg["spp"], max_bounces=cfg["max_bounces"], seed=cfg["seed"])
+            pt.render_frame(scene, w, h, **kw)
+            t0 = time.perf_counter()
+            host = pt.render_frame(scene, w, h, **kw)
+            line["config"]["host_frame_ms"] = (time.perf_counter() - t0) * 1e3
+            line["config"]["host_frame_note"] = ("ptgpu_render_frame: scene upload + kernel + "
+                                                 f"{3 * w * h / 1e6:.1f} MB download, library defaults")
         if world == 1 and not args.no_cpu_baseline:
             host_frame = frame.cpu().numpy()
             base_line, rmse = cpu_baseline(pt, scene, cfg, lambda rows: host_frame[rows])

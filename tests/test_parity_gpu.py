@@ -313,18 +313,23 @@ def test_schedule_is_measured_once_per_scene_and_cached(gpu, torch_cuda):
     torch = torch_cuda
     w, h, spp = 512, 512, 32
     kw = dict(spp=spp, max_bounces=4, seed=4)
-    with gpu.HostScene(5) as s, gpu.DeviceScene(s) as d:
-        owner = render_device(gpu, torch, d, w, h, flags=0x80, **kw)
-        gpu.host.reset_stats()
-        first = render_device(gpu, torch, d, w, h, **kw)      # pilot + remainder
-        n_first = gpu.host.read_stats().launches
-        gpu.host.reset_stats()
-        second = render_device(gpu, torch, d, w, h, **kw)     # cached choice
-        n_second = gpu.host.read_stats().launches
-        schedule = d.schedule
+    with gpu.HostScene(5) as s:
+        # a scene no other test uploads: choices are memoised by scene content
+        s.add_sphere((123.25, 456.5, 789.75), 0.5, 0)
+        with gpu.DeviceScene(s) as d:
+            owner = render_device(gpu, torch, d, w, h, flags=0x80, **kw)
+            gpu.host.reset_stats()
+            first = render_device(gpu, torch, d, w, h, **kw)      # pilots + remainder
+            n_first = gpu.host.read_stats().launches
+            gpu.host.reset_stats()
+            second = render_device(gpu, torch, d, w, h, **kw)     # remembered choice
+            n_second = gpu.host.read_stats().launches
+            schedule, scan = d.schedule, d.scan
+        with gpu.DeviceScene(s) as again:                         # same content, new handle
+            assert (again.schedule, again.scan) == (schedule, scan)
     assert np.array_equal(first, owner) and np.array_equal(second, owner)
     assert n_first > n_second                     # the pilot launches happened once
-    assert schedule == "sample-queue"
+    assert schedule == "sample-queue" and scan in ("screened linear", "bvh")
 
 
 def test_queue_frames_on_two_streams_share_the_scratch_safely(gpu, torch_cuda):
