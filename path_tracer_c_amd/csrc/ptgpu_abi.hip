@@ -205,11 +205,22 @@ uint64_t fnv1a64(const void *data, size_t n, uint64_t h = 0xCBF29CE484222325ull)
     return h;
 }
 
+// Second key: the scene's shape (object / triangle / material counts).  An
+// animated scene changes content every frame (the reference's RT loop does,
+// src/main.c:260-263) but not shape; it inherits the choice instead of paying
+// for pilots on every frame.
+uint64_t shape_key(const pt::SceneDesc &d) {
+    const uint32_t shape[4] = {d.n_obj, d.n_tri, d.n_mat, d.branching};
+    return fnv1a64(shape, sizeof shape, 0x9E3779B97F4A7C15ull);
+}
+
 void remember_choice(const ptgpu_scene *s) {
     std::lock_guard<std::mutex> guard(g_choice_mutex);
     if (g_choices.size() > 4096)
         g_choices.clear();
-    g_choices[s->content_hash] = Choice{s->queue_mode.load(), s->scan_choice.load()};
+    const Choice c{s->queue_mode.load(), s->scan_choice.load()};
+    g_choices[s->content_hash] = c;
+    g_choices[shape_key(s->desc)] = c;
 }
 } // namespace
 
@@ -372,14 +383,6 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
     }
     h->blob_bytes = blob.size();
     h->content_hash = fnv1a64(blob.data(), blob.size());
-    {
-        std::lock_guard<std::mutex> guard(g_choice_mutex);
-        auto known = g_choices.find(h->content_hash);
-        if (known != g_choices.end()) {
-            h->queue_mode.store(known->second.queue_mode);
-            h->scan_choice.store(known->second.scan_choice);
-        }
-    }
     const pt::F4 *dbase = reinterpret_cast<const pt::F4 *>(h->blob);
     h->desc.geom = dbase;
     h->desc.tri = dbase + n_obj;
@@ -432,6 +435,18 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
     h->desc.sky[1] = host->sky_color.y;
     h->desc.sky[2] = host->sky_color.z;
     h->desc.pad = 0;
+    {
+        std::lock_guard<std::mutex> guard(g_choice_mutex);
+        auto known = g_choices.find(h->content_hash);
+        if (known == g_choices.end())
+            known = g_choices.find(shape_key(h->desc));
+        if (known != g_choices.end()) {
+            h->queue_mode.store(known->second.queue_mode);
+            h->scan_choice.store(known->second.scan_choice);
+            if (h->scan_choice.load() == 2 && h->desc.bvh_nodes == nullptr)
+                h->scan_choice.store(-1); // inherited by shape, but no hierarchy here
+        }
+    }
     *out = h;
     return PTGPU_OK;
 }

@@ -566,6 +566,31 @@ def test_randomised_scenes_match_the_oracle(gpu, oracle, branching):
             assert np.array_equal(got, ref), (trial, w, h, spp, b, hex(flags), s.counts())
 
 
+@pytest.mark.parametrize("scale", [1e-20, 1e-12, 1e15], ids=["denormal r*r", "tiny", "huge"])
+def test_extreme_scales_match_the_oracle(gpu, oracle, scale):
+    """Radii of 1e-20 make r*r a binary32 denormal; 1e15 puts squared
+    distances near 1e33.  The device must treat denormals as IEEE (not flush
+    them) and take the generic sqrt/divide paths outside the fast ranges."""
+    rng = np.random.default_rng(21)
+    with gpu.HostScene() as s:
+        s.set_sky(0.6, 0.7, 0.9)
+        mats = [s.add_material(tuple(rng.uniform(0.3, 0.9, 3)), roughness=float(r))
+                for r in (0.0, 0.3, 1.0)]
+        glass = s.add_material((1, 1, 1), roughness=0.0, transparency=1.0)
+        for i in range(40):
+            c = (rng.uniform(-3, 3, 3) + np.array([0, 0, 6])) * scale
+            if i % 5 == 4:
+                s.add_triangle(tuple(c), tuple(c + rng.uniform(-1, 1, 3) * scale),
+                               tuple(c + rng.uniform(-1, 1, 3) * scale), mats[i % 3])
+            else:
+                s.add_sphere(tuple(c), float(rng.uniform(0.3, 1.0) * scale), glass if i % 7 == 0 else mats[i % 3])
+        ref, rays = oracle.render_rows(s, 72, 48, spp=4, max_bounces=6, seed=2)
+        assert rays > 72 * 48 * 4 * 1.2                 # things are actually hit
+        for flags in (0x10, 0x20, 0x100):
+            got = gpu.render_frame(s, 72, 48, spp=4, max_bounces=6, seed=2, flags=flags)
+            assert np.array_equal(got, ref), hex(flags)
+
+
 def test_kernel_limits_at_their_maximum(gpu, oracle):
     """The deepest bounce stacks the two kernels accept (62 and 14)."""
     with mirror_room(gpu) as s:
