@@ -552,8 +552,9 @@ def _random_scene(gpu, rng, branching):
 
 @pytest.mark.parametrize("branching", [False, True], ids=["paths", "trees"])
 def test_randomised_scenes_match_the_oracle(gpu, oracle, branching):
-    rng = np.random.default_rng(2025 + int(branching))
-    for trial in range(40 if not branching else 16):
+    rng = np.random.default_rng(int(os.environ.get("PT_FUZZ_SEED", "2025")) + int(branching))
+    trials = int(os.environ.get("PT_FUZZ_TRIALS", "40"))   # set higher for a fuzz campaign
+    for trial in range(trials if not branching else max(1, trials * 2 // 5)):
         with _random_scene(gpu, rng, branching) as s:
             w, h = int(rng.integers(8, 70)), int(rng.integers(5, 40))
             spp = int(rng.integers(1, 5))
