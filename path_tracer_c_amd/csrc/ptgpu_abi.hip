@@ -699,6 +699,25 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
     if (mode < 0 && !can_measure)
         mode = kPixelOwner;
 
+    // A small row set (a shard of a frame split over many GPUs) does not give
+    // the pixel-owner kernel enough waves: 135 rows of 1920 pixels are 4050
+    // waves for 8192 wave slots, and this kernel slows down as occupancy is
+    // taken away (66 -> 95 ms at half occupancy); a second, nearly empty
+    // round of waves is as bad.  The sample queue always fills the device
+    // (its unit of work is a sample), at the price of 32 bytes per sample.
+    if (mode == kPixelOwner && !tree && a.counters != nullptr && total_spp >= 16 &&
+        !(p->flags & PTGPU_FLAG_PIXEL_OWNER)) {
+        DeviceScratch *probe = nullptr;
+        if (scratch_for_current_device(&probe) == PTGPU_OK && probe->max_waves > 0) {
+            const double fill = (double)((npix + 63u) / 64u) / (double)probe->max_waves;
+            const double owner_efficiency = fill / std::ceil(fill);
+            // measured on C2 shards: one round of waves (fill ~1) is 11 %
+            // slower than the queue, half a round 27 %, two rounds equal
+            if (fill < 1.5 || (fill < 4.0 && owner_efficiency < 0.85))
+                mode = kSampleQueue;
+        }
+    }
+
     if (mode == kPixelOwner) { // the one-launch fast path, no scratch involved
         a.frame = d_frame;  // exactly one of the two is non-null
         a.accum = d_accum;
