@@ -163,8 +163,9 @@ int ptgpu_scene_upload(const scene *host_scene, ptgpu_scene **out);
 void ptgpu_scene_free(ptgpu_scene *s);
 /* 1 if some material has 0 < transparency < 1 (needs the tree kernel). */
 int ptgpu_scene_is_branching(const ptgpu_scene *s);
-/* Schedule remembered for this scene: 0 not measured yet, 1 pixel-owner,
- * 2 sample-queue (see PTGPU_FLAG_PIXEL_OWNER / _SAMPLE_QUEUE). */
+/* Schedule of this scene's latest render (before any render: the remembered
+ * choice): 0 not measured yet, 1 pixel-owner, 2 sample-queue (see
+ * PTGPU_FLAG_PIXEL_OWNER / _SAMPLE_QUEUE). */
 int ptgpu_scene_schedule(const ptgpu_scene *s);
 /* Scan form remembered for this scene (measured on the same occasion):
  * 0 not measured yet, 1 plain, 2 screened linear, 3 BVH. */

@@ -184,6 +184,7 @@ struct ptgpu_scene {
     // Scan form measured best for this scene on the same occasion:
     // -1 not measured, else 0 plain / 1 screened / 2 BVH.
     mutable std::atomic<int> scan_choice{-1};
+    mutable std::atomic<int> last_mode{-1}; // schedule the latest render really used
     uint64_t content_hash = 0; // of the uploaded records: key of the choice memo
 };
 
@@ -464,7 +465,10 @@ void ptgpu_scene_free(ptgpu_scene *s) {
 int ptgpu_scene_schedule(const ptgpu_scene *s) {
     if (s == nullptr)
         return fail(PTGPU_ERR_INVALID, "scene is NULL");
-    return s->queue_mode.load() + 1; // 0 not measured, 1 pixel-owner, 2 sample-queue
+    // what the latest render of this scene used (it can differ from the
+    // remembered per-scene choice: small row sets go to the queue regardless)
+    const int used = s->last_mode.load();
+    return (used >= 0 ? used : s->queue_mode.load()) + 1;
 }
 
 int ptgpu_scene_scan(const ptgpu_scene *s) {
@@ -718,6 +722,8 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         }
     }
 
+    if (mode >= 0)
+        s->last_mode.store(mode);
     if (mode == kPixelOwner) { // the one-launch fast path, no scratch involved
         a.frame = d_frame;  // exactly one of the two is non-null
         a.accum = d_accum;
@@ -862,6 +868,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         // full-length launch reaches, because their tail weighs more)
         mode = recovered > 3.0 * 480.0 ? kSampleQueue : kPixelOwner;
         s->queue_mode.store(mode);
+        s->last_mode.store(mode);
         remember_choice(s);
     }
 
