@@ -130,6 +130,13 @@ typedef struct ptgpu_params {
                                sample before they settle it together.  0 =
                                chosen from the scene size; 1 = per-lane path
                                regeneration; 64 = sample-synchronous waves */
+    uint32_t lanes_per_pixel; /* scheduling only, never changes the image:
+                               lanes of a wavefront sharing one pixel's
+                               samples in the pixel-owner schedule (the sum
+                               stays in sample order).  0 = chosen from the
+                               row set's size (more than 1 only when it is
+                               too small to fill the device); else a power
+                               of two, 1..64 */
 } ptgpu_params;
 
 typedef struct ptgpu_stats {

@@ -146,6 +146,7 @@ class Params(C.Structure):
         ("flags", C.c_uint32),
         ("block_threads", C.c_uint32),
         ("settle_lanes", C.c_uint32),
+        ("lanes_per_pixel", C.c_uint32),
     ]
 
 

@@ -309,6 +309,75 @@ run_paths(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
 }
 
 // ---------------------------------------------------------------------------
+// The same, with k = 2, 4, ... lanes per pixel (consecutive lanes of a wave).
+//
+// A row set that is too small to fill the device with one lane per pixel (a
+// shard of a frame split over many GPUs, a small image) gets k lanes per
+// pixel: in round r lane q of a pixel traces sample r*k + q.  The wave is
+// sample-synchronous here: when every lane has parked, all unwind, and the
+// pixel's first lane adds the k clamped samples IN SAMPLE ORDER, fetching its
+// partners' values with cross-lane reads -- so the sum is the very same
+// sequence of binary32 additions one lane would have made, and the image is
+// unchanged.  No HBM traffic, k times the waves.
+// ---------------------------------------------------------------------------
+template <int kScan>
+__device__ __forceinline__ void
+run_paths_split(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
+                uint32_t stack_stride, const ScreenQueue queue, V3 d0,
+                uint32_t pixel, uint32_t spp, uint32_t k, uint32_t q, V3 sky,
+                V3 &sum, uint32_t &rays, uint32_t &scans, uint32_t &iters,
+                uint32_t &samples_done) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t group = lane - q; // first lane of this pixel's group
+    const uint32_t rounds = (a.spp + k - 1u) / k;
+    PathState p;
+    p.r = splat(0.0f);
+    p.live = p.parked = false;
+
+    Hit h_primary = Hit{-1.0f, -1};
+    if (a.share_primary && spp != 0u) {
+        h_primary = scan_scene<kScan>(rec, splat(0.0f), d0, queue);
+        ++scans;
+    }
+
+    for (uint32_t round = 0; round < rounds; ++round) { // wave-uniform
+        const uint32_t s = round * k + q;
+        p.o = splat(0.0f);
+        p.d = d0;
+        p.depth = 0;
+        p.rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset + s);
+        p.live = s < spp;
+        p.parked = false;
+        const bool mine = p.live; // this lane traces a sample in this round
+
+        while (__any(p.live)) {
+            ++iters;
+            const bool all_at_start = a.share_primary && !__any(p.live && p.depth != 0u);
+            if (p.live) {
+                ++rays;
+                if (!all_at_start)
+                    ++scans;
+                advance_path<kScan>(rec, a, stack, stack_stride, queue, sky, p,
+                                    all_at_start, h_primary);
+            }
+        }
+        V3 sample = splat(0.0f);
+        if (mine) {
+            sample = unwind_path(rec, stack, stack_stride, p);
+            ++samples_done;
+        }
+        // the pixel's first lane adds samples round*k .. round*k + k-1, in order
+        for (uint32_t i = 0; i < k; ++i) {
+            const V3 other = V3{__shfl(sample.x, (int)(group + i), 64),
+                                __shfl(sample.y, (int)(group + i), 64),
+                                __shfl(sample.z, (int)(group + i), 64)};
+            if (round * k + i < spp)
+                sum = sum + other;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Branching paths: explicit depth-first evaluation of the recursion tree.
 // ---------------------------------------------------------------------------
 constexpr int kTreeFrames = 16; // PTGPU_MAX_BOUNCES_TREE + 2
@@ -599,8 +668,12 @@ __global__ void __launch_bounds__(1024) pt_megakernel(const LaunchArgs a) {
     const WorkgroupScene w = stage_scene<kLds>(a, lds_dyn, tid, nthreads);
 
     const uint64_t npix = (uint64_t)a.num_rows * a.framew;
-    const uint64_t j = (uint64_t)blockIdx.x * nthreads + tid;
+    const uint32_t k = a.lanes_per_pixel; // 1, or a power of two <= 64
+    const uint64_t t = (uint64_t)blockIdx.x * nthreads + tid;
+    const uint64_t j = t / k;             // local pixel
+    const uint32_t q = (uint32_t)(t - j * k); // this lane's place among the pixel's k lanes
     const bool valid = j < npix;
+    const bool owner = valid && q == 0u;  // holds the sum, reads and writes the pixel
     const PixelSite ps = pixel_site(a, valid ? j : 0u);
     const V3 sky = V3{a.scene.sky[0], a.scene.sky[1], a.scene.sky[2]};
 
@@ -608,30 +681,35 @@ __global__ void __launch_bounds__(1024) pt_megakernel(const LaunchArgs a) {
     V3 sum = splat(0.0f);
     float had = 0.0f;
     const uint64_t acc_at = a.accum_local ? j : ps.out_pixel;
-    if (a.accum != nullptr && valid) {
+    if (a.accum != nullptr && owner) {
         const float4 prev = reinterpret_cast<const float4 *>(a.accum)[acc_at];
         sum = V3{prev.x, prev.y, prev.z};
         had = prev.w;
     }
     uint32_t rays = 0, scans = 0, iters = 0;
     const uint32_t spp = valid ? a.spp : 0u;
+    uint32_t samples_done = owner ? spp : 0u;
     if (kTree) {
         run_tree(w.rec, a, ps.d0, ps.pixel, spp, sky, sum, rays, iters);
         scans = rays;
-    } else {
+    } else if (k == 1u) {
         run_paths<kScan>(w.rec, a, w.stack, nthreads, w.queue, ps.d0, ps.pixel,
-                           spp, sky, sum, rays, scans, iters);
+                         spp, sky, sum, rays, scans, iters);
+    } else {
+        samples_done = 0u;
+        run_paths_split<kScan>(w.rec, a, w.stack, nthreads, w.queue, ps.d0, ps.pixel,
+                               spp, k, q, sky, sum, rays, scans, iters, samples_done);
     }
 
     // ---- write back ------------------------------------------------------------
     if (a.accum != nullptr) {
-        if (valid)
+        if (owner)
             reinterpret_cast<float4 *>(a.accum)[acc_at] =
                 make_float4(sum.x, sum.y, sum.z, had + (float)a.spp);
     } else {
-        store_rgb8(a.frame, sum, (float)a.spp, ps.out_pixel, valid, tid & 63u);
+        store_rgb8(a.frame, sum, (float)a.spp, ps.out_pixel, owner, tid & 63u);
     }
-    count_wave(a.counters, rays, scans, spp, iters, tid & 63u);
+    count_wave(a.counters, rays, scans, samples_done, iters, tid & 63u);
 }
 
 // ---------------------------------------------------------------------------
@@ -936,7 +1014,8 @@ hipError_t launch_megakernel(const LaunchArgs &a, uint32_t block, bool tree,
     const uint64_t npix = (uint64_t)a.num_rows * a.framew;
     if (npix == 0 || a.spp == 0)
         return hipSuccess;
-    const uint32_t grid = (uint32_t)((npix + block - 1) / block);
+    const uint64_t lanes = npix * (tree || a.lanes_per_pixel == 0 ? 1u : a.lanes_per_pixel);
+    const uint32_t grid = (uint32_t)((lanes + block - 1) / block);
     const size_t lds = megakernel_lds_bytes(a, block, tree);
     if (tree)
         return a.scene_in_lds
@@ -1015,6 +1094,19 @@ extern "C" int ptgpu_debug_stamps(unsigned long long out[4], int reset) {
     if (reset) {
         unsigned long long zero[4] = {0, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof zero) != hipSuccess)
+            return -1;
+    }
+    return 0;
+}
+#endif
+
+#ifdef PT_BVH_PROFILE
+extern "C" int ptgpu_debug_bvh_profile(unsigned long long out[8], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_profile), sizeof(unsigned long long) * 8) != hipSuccess)
+        return -1;
+    if (reset) {
+        unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_profile), zero, sizeof zero) != hipSuccess)
             return -1;
     }
     return 0;

@@ -286,8 +286,27 @@ PT_HD void test_object_unordered(const SceneRecords &rec, V3 o, V3 d, uint32_t i
     }
 }
 
+// Diagnostic build only (make EXTRA_HIPFLAGS=-DPT_BVH_PROFILE): lane-passes and
+// wave-passes of the three loops of the BVH scan, summed into device words no
+// kernel reads (tools/bvh_profile.py prints them).  Not in the shipped library.
+#ifdef PT_BVH_PROFILE
+__device__ unsigned long long g_bvh_profile[8];
+#define PT_BVH_COUNT(slot, active)                                             \
+    do {                                                                       \
+        prof[slot] += (uint32_t)__popcll(__ballot(active));                    \
+        prof[(slot) + 1] += 1u;                                                \
+    } while (0)
+#else
+#define PT_BVH_COUNT(slot, active)
+#endif
+
 __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3 d,
                                                const ScreenQueue q) {
+#ifdef PT_BVH_PROFILE
+    uint32_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    prof[6] = (uint32_t)__popcll(__ballot(true));
+    prof[7] = 1u;
+#endif
     UnorderedBest u;
     u.best = __builtin_inff();
     u.best_idx = -1;
@@ -307,6 +326,7 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
 
     auto resolve = [&]() {
         for (uint32_t *rd = first; __any(rd < wr); rd += q.stride) {
+            PT_BVH_COUNT(4, rd < wr);
             if (rd < wr) {
                 const uint32_t idx = *rd;
                 test_object_unordered(rec, o, d, idx, rec.geom[idx], u);
@@ -364,6 +384,7 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
             // leaf code below then runs once for many lanes instead of on
             // every pass for a few
             while (__any(cur != kDone && !(cur & kLeafRef))) {
+                PT_BVH_COUNT(0, cur != kDone && !(cur & kLeafRef));
                 if (cur != kDone && !(cur & kLeafRef)) {
                     const F4 l_lo = rec.bvh_nodes[4u * cur + 0u];
                     const F4 l_hi = rec.bvh_nodes[4u * cur + 1u];
@@ -389,6 +410,7 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
                     }
                 }
             }
+            PT_BVH_COUNT(2, cur != kDone);
             if (cur != kDone) { // a leaf
                 const uint32_t count = (cur >> 28) & 7u;
                 const uint32_t at = cur & 0x0FFFFFFFu;
@@ -437,6 +459,11 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
         if (poisoned)
             h = closest_hit(rec, o, d);
     }
+#ifdef PT_BVH_PROFILE
+    if ((threadIdx.x & 63u) == 0u)
+        for (int k = 0; k < 8; ++k)
+            atomicAdd(&g_bvh_profile[k], (unsigned long long)prof[k]);
+#endif
     return h;
 }
 

@@ -185,6 +185,10 @@ struct ptgpu_scene {
     // -1 not measured, else 0 plain / 1 screened / 2 BVH.
     mutable std::atomic<int> scan_choice{-1};
     mutable std::atomic<int> last_mode{-1}; // schedule the latest render really used
+    // Do nearly all paths run to the bounce limit (closed scene)?  -1 not
+    // measured, 0 no, 1 yes: then a sample-synchronous wave wastes nothing, and
+    // the pixel-owner kernel may put several lanes on a pixel freely.
+    mutable std::atomic<int> full_depth{-1};
     uint64_t content_hash = 0; // of the uploaded records: key of the choice memo
 };
 
@@ -192,7 +196,7 @@ namespace {
 // Choices survive the handle: a caller that uploads the same scene again (the
 // one-shot ptgpu_render_frame does, every frame) finds them by content.
 struct Choice {
-    int queue_mode, scan_choice;
+    int queue_mode, scan_choice, full_depth;
 };
 std::mutex g_choice_mutex;
 std::map<uint64_t, Choice> g_choices;
@@ -219,7 +223,7 @@ void remember_choice(const ptgpu_scene *s) {
     std::lock_guard<std::mutex> guard(g_choice_mutex);
     if (g_choices.size() > 4096)
         g_choices.clear();
-    const Choice c{s->queue_mode.load(), s->scan_choice.load()};
+    const Choice c{s->queue_mode.load(), s->scan_choice.load(), s->full_depth.load()};
     g_choices[s->content_hash] = c;
     g_choices[shape_key(s->desc)] = c;
 }
@@ -266,6 +270,7 @@ int ptgpu_params_from_env(ptgpu_params *p) {
     env_u32("PTGPU_BLOCK", &p->block_threads);
     env_u32("PTGPU_FLAGS", &p->flags);
     env_u32("PTGPU_SETTLE", &p->settle_lanes);
+    env_u32("PTGPU_LANES_PER_PIXEL", &p->lanes_per_pixel);
     if (const char *deg = std::getenv("PTGPU_FOV_DEG")) {
         char *end = nullptr;
         double d = std::strtod(deg, &end);
@@ -444,6 +449,7 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
         if (known != g_choices.end()) {
             h->queue_mode.store(known->second.queue_mode);
             h->scan_choice.store(known->second.scan_choice);
+            h->full_depth.store(known->second.full_depth);
             if (h->scan_choice.load() == 2 && h->desc.bvh_nodes == nullptr)
                 h->scan_choice.store(-1); // inherited by shape, but no hierarchy here
         }
@@ -585,6 +591,9 @@ int prepare_launch(const ptgpu_scene *s, size_t framew, size_t frameh,
         a->screened = 2u;
     }
     a->share_primary = (p->flags & PTGPU_FLAG_NO_PRIMARY_SHARE) ? 0u : 1u;
+    if (p->lanes_per_pixel > 64u || (p->lanes_per_pixel & (p->lanes_per_pixel - 1u)) != 0u)
+        return fail(PTGPU_ERR_INVALID, "lanes_per_pixel must be 0 or a power of two up to 64");
+    a->lanes_per_pixel = 1u; // render_common decides
     if (p->settle_lanes > 64u)
         return fail(PTGPU_ERR_INVALID, "settle_lanes must be 0..64");
     a->settle_lanes = p->settle_lanes ? p->settle_lanes : auto_settle_lanes(s->desc);
@@ -703,24 +712,42 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
     if (mode < 0 && !can_measure)
         mode = kPixelOwner;
 
-    // A small row set (a shard of a frame split over many GPUs) does not give
-    // the pixel-owner kernel enough waves: 135 rows of 1920 pixels are 4050
-    // waves for 8192 wave slots, and this kernel slows down as occupancy is
-    // taken away (66 -> 95 ms at half occupancy); a second, nearly empty
-    // round of waves is as bad.  The sample queue always fills the device
-    // (its unit of work is a sample), at the price of 32 bytes per sample.
-    if (mode == kPixelOwner && !tree && a.counters != nullptr && total_spp >= 16 &&
-        !(p->flags & PTGPU_FLAG_PIXEL_OWNER)) {
+    // How many lanes share a pixel in the pixel-owner kernel (pt_kernels.hip,
+    // run_paths_split).  More lanes = more, shorter waves: a small row set (a
+    // shard of a frame split over many GPUs, a small image) fills the device,
+    // and a large one ends with a shorter tail of half-empty wave rounds
+    // (measured, configuration 2: 63.3 ms with 1 lane, 59.0 with 8; a 135-row
+    // shard 11.9 -> 8.9).  The price: such waves are sample-synchronous, which
+    // wastes lane-passes when path lengths differ.  So: as many lanes as it
+    // takes to reach ~24 rounds of waves when the scene is known to run its
+    // paths to the bounce limit, and otherwise only as many as fit into
+    // wave slots that would stay empty.
+    auto choose_lanes = [&](bool may_fall_back_to_queue) {
+        if (mode != kPixelOwner || tree)
+            return;
         DeviceScratch *probe = nullptr;
-        if (scratch_for_current_device(&probe) == PTGPU_OK && probe->max_waves > 0) {
+        if (p->lanes_per_pixel != 0u) {
+            a.lanes_per_pixel = p->lanes_per_pixel;
+        } else if (scratch_for_current_device(&probe) == PTGPU_OK && probe->max_waves > 0) {
             const double fill = (double)((npix + 63u) / 64u) / (double)probe->max_waves;
+            const double want = s->full_depth.load() == 1 ? 24.0 : 1.0;
+            uint32_t k = 1u;
+            while (fill * (2u * k) <= want * 1.34 && k < 16u && 2u * k <= total_spp)
+                k *= 2u;
+            a.lanes_per_pixel = k;
+            // Still under-filled with one lane per pixel (open scene, few
+            // samples): the sample queue fills the device whatever the row
+            // set, at the price of 32 bytes per sample.  Measured on C2
+            // shards: one round of waves (fill ~1) is 11 % slower than the
+            // queue, half a round 27 %, two rounds equal.
             const double owner_efficiency = fill / std::ceil(fill);
-            // measured on C2 shards: one round of waves (fill ~1) is 11 %
-            // slower than the queue, half a round 27 %, two rounds equal
-            if (fill < 1.5 || (fill < 4.0 && owner_efficiency < 0.85))
+            if (may_fall_back_to_queue && k == 1u && a.counters != nullptr && total_spp >= 16 &&
+                !(p->flags & PTGPU_FLAG_PIXEL_OWNER) &&
+                (fill < 1.5 || (fill < 4.0 && owner_efficiency < 0.85)))
                 mode = kSampleQueue;
         }
-    }
+    };
+    choose_lanes(true);
 
     if (mode >= 0)
         s->last_mode.store(mode);
@@ -867,9 +894,11 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         // (3x, not 1x: 4-sample pilot launches under-state the utilisation a
         // full-length launch reaches, because their tail weighs more)
         mode = recovered > 3.0 * 480.0 ? kSampleQueue : kPixelOwner;
+        s->full_depth.store(rays_per_sample >= 0.93 * ((double)a.max_bounces + 1.0) ? 1 : 0);
         s->queue_mode.store(mode);
         s->last_mode.store(mode);
         remember_choice(s);
+        choose_lanes(false); // for the rest of this frame
     }
 
     if (mode == kPixelOwner || done_spp >= total_spp) {

@@ -238,6 +238,49 @@ def test_scheduling_knobs_never_change_the_image(gpu, oracle, flags, settle):
         assert np.array_equal(got, ref), (cfg, flags, settle)
 
 
+@pytest.mark.parametrize("k", [2, 4, 8, 16, 64])
+def test_lanes_per_pixel_never_changes_the_image(gpu, oracle, k):
+    """k lanes share a pixel's samples; the first adds them in sample order
+    (spp not a multiple of k, fewer samples than lanes, accumulator passes)."""
+    for cfg, w, h, spp, b, flags in [(0, 96, 60, 7, 4, 0x80), (2, 50, 36, 19, 8, 0x80),
+                                     (5, 64, 36, 5, 8, 0x480), (2, 33, 17, 3, 6, 0x280)]:
+        with gpu.HostScene(cfg) as s:
+            got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=21, flags=flags,
+                                   lanes_per_pixel=k)
+            ref, _ = oracle.render_rows(s, w, h, spp=spp, max_bounces=b, seed=21)
+        assert np.array_equal(got, ref), (cfg, k)
+
+
+def test_lanes_per_pixel_progressive_and_stats(gpu):
+    """Accumulator passes with several lanes per pixel equal the one-lane
+    passes bit for bit, and the counters still count every sample once."""
+    import torch
+    w, h = 64, 40
+    with gpu.HostScene(2) as s, gpu.DeviceScene(s) as d:
+        st = torch.cuda.current_stream().cuda_stream
+        accs = []
+        for k in (1, 4):
+            acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+            gpu.host.reset_stats()
+            for i in range(3):
+                p = gpu.make_params(spp=5, sample_offset=5 * i, max_bounces=6, seed=3,
+                                    flags=0x80, lanes_per_pixel=k)
+                d.accumulate(acc.data_ptr(), w, h, p, st)
+            torch.cuda.synchronize()
+            stats = gpu.host.read_stats()
+            assert stats.samples == w * h * 15
+            accs.append((acc.cpu(), stats.rays))
+        assert torch.equal(accs[0][0], accs[1][0])
+        assert accs[0][1] == accs[1][1]
+
+
+def test_bad_lanes_per_pixel_is_refused(gpu):
+    with gpu.HostScene(0) as s:
+        for k in (3, 65, 128):
+            with pytest.raises(gpu.PtgpuError):
+                gpu.render_frame(s, 16, 16, lanes_per_pixel=k)
+
+
 def test_screened_scan_with_many_triangles_and_nan_radius(gpu, oracle):
     """Triangles are always queued by the screen; a NaN radius must stay a
     sphere record (sign bit of r*r cleared at upload)."""
@@ -505,13 +548,19 @@ def test_primary_scan_sharing_is_invisible_and_accounted(gpu, oracle):
     with gpu.HostScene(2) as s:
         ref, rays = oracle.render_rows(s, w, h, spp=spp, max_bounces=8, seed=6)
         gpu.host.reset_stats()
-        shared = gpu.render_frame(s, w, h, spp=spp, max_bounces=8, seed=6, flags=0x80)
+        shared = gpu.render_frame(s, w, h, spp=spp, max_bounces=8, seed=6, flags=0x80,
+                                  lanes_per_pixel=1)
         st_shared = gpu.host.read_stats()
+        gpu.host.reset_stats()
+        split = gpu.render_frame(s, w, h, spp=spp, max_bounces=8, seed=6, flags=0x80,
+                                 lanes_per_pixel=4)      # each of 4 lanes scans once for 4 samples
+        st_split = gpu.host.read_stats()
         gpu.host.reset_stats()
         plain = gpu.render_frame(s, w, h, spp=spp, max_bounces=8, seed=6, flags=0x280)
         st_plain = gpu.host.read_stats()
-    assert np.array_equal(shared, ref) and np.array_equal(plain, ref)
-    assert st_shared.rays == rays and st_plain.rays == rays
+    assert np.array_equal(shared, ref) and np.array_equal(plain, ref) and np.array_equal(split, ref)
+    assert st_shared.rays == rays and st_plain.rays == rays and st_split.rays == rays
+    assert 0 < rays - st_split.scans <= w * h * (spp - 4)
     assert st_plain.scans == rays
     assert w * h <= rays - st_shared.scans <= w * h * (spp - 1)   # at most one scan saved per sample
 

@@ -1,0 +1,29 @@
+"""Diagnostic: SIMD efficiency of the three loops of the BVH scan (inner-node
+steps, leaf passes, exact-test resolve passes) on configuration 5.
+Needs a profiling build:  make -B EXTRA_HIPFLAGS=-DPT_BVH_PROFILE path_tracer_c_amd/lib/libptgpu.so
+(rebuild without the flag afterwards; never shipped)."""
+import ctypes as C
+import sys
+sys.path.insert(0, '.')
+import torch
+import path_tracer_c_amd as pt
+
+lib = pt.lib()
+fn = lib.ptgpu_debug_bvh_profile
+fn.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+out = (C.c_ulonglong * 8)()
+c = pt.CONFIGS[5]
+w, h, spp = c['width'], c['height'], 16
+with pt.HostScene(c['scene']) as s, pt.DeviceScene(s) as d:
+    st = torch.cuda.current_stream().cuda_stream
+    img = torch.zeros((h, w, 3), dtype=torch.uint8, device='cuda')
+    for name, flags, k in (("owner k=1", 0x480, 1), ("owner k=64", 0x480, 64), ("queue", 0x500, 1)):
+        fn(out, 1)
+        p = pt.make_params(spp=spp, max_bounces=c['max_bounces'], seed=1, flags=flags, lanes_per_pixel=k)
+        d.render(img.data_ptr(), w, h, p, st); torch.cuda.synchronize()
+        fn(out, 0)
+        v = [float(x) for x in out]
+        calls = v[7]
+        print(f"{name:11s} scans/wave-call: lanes {v[6]/calls:5.1f} | inner steps: {v[1]/calls:6.1f} wave-passes, "
+              f"lane use {v[0]/(64*v[1]):.3f} | leaf passes {v[3]/calls:5.1f}, lane use {v[2]/(64*v[3]):.3f} | "
+              f"resolve passes {v[5]/calls:5.1f}, lane use {v[4]/(64*v[5]):.3f}", flush=True)

@@ -13,13 +13,16 @@ with pt.HostScene(c['scene']) as s, pt.DeviceScene(s) as d:
         sh = tiles.shard_rows(h, world, 0, 8)
         pad = tiles.max_shard_rows(h, world, 8)
         out = torch.zeros((pad, w, 3), dtype=torch.uint8, device='cuda')
-        for name, flags in (("default", 0x201), ("owner", 0x281), ("queue", 0x301)):
+        for name, flags, k in (("default", 0x201, 0), ("owner", 0x281, 1), ("queue", 0x301, 1),
+                               ("owner k=2", 0x281, 2), ("owner k=4", 0x281, 4), ("owner k=8", 0x281, 8),
+                               ("owner k=16", 0x281, 16), ("owner k=32", 0x281, 32)):
             p = pt.make_params(spp=c['spp'], max_bounces=8, seed=1, row_begin=sh.row_begin, num_rows=sh.num_rows,
-                               tile_rows=8 if world > 1 else 0, tile_stride=sh.tile_stride, flags=flags)
+                               tile_rows=8 if world > 1 else 0, tile_stride=sh.tile_stride, flags=flags,
+                               lanes_per_pixel=k)
             d.render(out.data_ptr(), w, h, p, st); torch.cuda.synchronize()
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3): d.render(out.data_ptr(), w, h, p, st)
             e1.record(); torch.cuda.synchronize()
             ok = bool(torch.equal(out[:sh.num_rows], full[sh.global_rows()]))
-            print(f"world {world}: rank-0 shard {sh.num_rows} rows  {name:8s} {e0.elapsed_time(e1)/3:7.2f} ms  (x{world} = {e0.elapsed_time(e1)/3*world:6.1f})  same-as-full {ok}", flush=True)
+            print(f"world {world}: rank-0 shard {sh.num_rows} rows  {name:10s} {e0.elapsed_time(e1)/3:7.2f} ms  (x{world} = {e0.elapsed_time(e1)/3*world:6.1f})  same-as-full {ok}", flush=True)
