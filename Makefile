@@ -23,7 +23,7 @@ CFLAGS   := -std=gnu2x -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude
 
 HOST_OBJS := $(BUILD)/scene.o $(BUILD)/vector.o $(BUILD)/bitmap.o $(BUILD)/scenes.o
 HIP_OBJS  := $(BUILD)/pt_kernels.o $(BUILD)/ptgpu_abi.o
-DEV_HDRS  := $(wildcard $(CSRC)/device/*.h) $(wildcard include/*.h)
+DEV_HDRS  := $(wildcard $(CSRC)/device/*.h) $(wildcard $(CSRC)/*.hpp) $(wildcard include/*.h)
 
 all: $(LIBDIR)/libptgpu.so oracle bin/ptrender
 

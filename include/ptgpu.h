@@ -95,6 +95,11 @@ extern "C" {
                                          of scanning every object.  Candidates
                                          still get the reference's exact tests
                                          and accept rule: same image */
+#define PTGPU_FLAG_WHOLE_WALKS 0x800u   /* scheduling only: in the sample-queue
+                                         schedule with the BVH scan, let each
+                                         wave finish its 64 walks together (the
+                                         older form) instead of handing a lane
+                                         its next ray as soon as its walk ends */
 #define PTGPU_FLAG_NO_PRIMARY_SHARE 0x200u /* scheduling only: scan the scene
                                          for the primary ray of every sample,
                                          as the reference does, instead of once

@@ -40,6 +40,7 @@ FLAG_SAMPLE_QUEUE = 0x100
 FLAG_NO_PRIMARY_SHARE = 0x200
 FLAG_SCAN_BVH = 0x400
 FLAG_SCAN_SCREENED = 0x20
+FLAG_WHOLE_WALKS = 0x800
 
 MAX_BOUNCES_PATH = 62
 MAX_BOUNCES_TREE = 14

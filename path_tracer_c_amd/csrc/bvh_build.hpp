@@ -78,30 +78,114 @@ struct Builder {
         return all;
     }
 
-    // emits the subtree over items[begin, end); returns its ref and box
-    uint32_t build(uint32_t begin, uint32_t end, uint32_t level, Box &box) {
-        box = bounds(begin, end);
-        const uint32_t n = end - begin;
-        if (n <= kLeafMax) {
-            const uint32_t ref = kBvhLeafBit | (n << 28) | (uint32_t)out.order.size();
-            for (uint32_t k = begin; k < end; ++k)
-                out.order.push_back(items[k]);
-            return ref;
+    static double half_area(const Box &b) {
+        const double dx = (double)b.hi[0] - b.lo[0], dy = (double)b.hi[1] - b.lo[1],
+                     dz = (double)b.hi[2] - b.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    static void grow(Box &all, const Box &b) {
+        for (int a = 0; a < 3; ++a) {
+            all.lo[a] = std::min(all.lo[a], b.lo[a]);
+            all.hi[a] = std::max(all.hi[a], b.hi[a]);
         }
-        out.depth = std::max(out.depth, level + 1);
-        // split at the median of the centres along their widest axis (objects
-        // sharing one centre cannot be split spatially: halved by index)
+    }
+    static Box empty_box() {
+        Box all;
+        for (int a = 0; a < 3; ++a) {
+            all.lo[a] = std::numeric_limits<float>::infinity();
+            all.hi[a] = -std::numeric_limits<float>::infinity();
+        }
+        return all;
+    }
+
+    // Permutes items[begin, end) and returns the split position.  Surface-area
+    // heuristic over 16 bins of the centres per axis: the split that minimises
+    // area(left) * |left| + area(right) * |right|, so that a huge object (a
+    // ground sphere of radius 1000 among unit spheres) is set apart near the
+    // root instead of inflating every box above its leaf.  Below kSahLevels,
+    // or when the centres cannot be separated, the median along the widest
+    // axis (by index if all centres coincide), which bounds the depth.
+    static constexpr uint32_t kSahLevels = 24;
+    static constexpr int kBins = 16;
+    uint32_t choose_split(uint32_t begin, uint32_t end, uint32_t level) {
+        const uint32_t n = end - begin;
         float clo[3], chi[3];
         for (int a = 0; a < 3; ++a) {
             clo[a] = std::numeric_limits<float>::infinity();
             chi[a] = -std::numeric_limits<float>::infinity();
         }
-        for (uint32_t k = begin; k < end; ++k) {
-            const Box &b = boxes[items[k]];
+        auto centre = [&](uint32_t item, int a) {
+            return 0.5f * boxes[item].lo[a] + 0.5f * boxes[item].hi[a];
+        };
+        for (uint32_t k = begin; k < end; ++k)
             for (int a = 0; a < 3; ++a) {
-                const float c = 0.5f * b.lo[a] + 0.5f * b.hi[a];
+                const float c = centre(items[k], a);
                 clo[a] = std::min(clo[a], c);
                 chi[a] = std::max(chi[a], c);
+            }
+        if (level < kSahLevels) {
+            double best_cost = std::numeric_limits<double>::infinity();
+            int best_axis = -1, best_plane = 0;
+            for (int a = 0; a < 3; ++a) {
+                if (!(chi[a] > clo[a]))
+                    continue;
+                const double scale = (double)kBins / ((double)chi[a] - clo[a]);
+                auto bin_of = [&](uint32_t item) {
+                    int b = (int)(((double)centre(item, a) - clo[a]) * scale);
+                    return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                };
+                Box bin_box[kBins];
+                uint32_t bin_n[kBins];
+                for (int b = 0; b < kBins; ++b) {
+                    bin_box[b] = empty_box();
+                    bin_n[b] = 0;
+                }
+                for (uint32_t k = begin; k < end; ++k) {
+                    const int b = bin_of(items[k]);
+                    grow(bin_box[b], boxes[items[k]]);
+                    ++bin_n[b];
+                }
+                double right_area[kBins];
+                uint32_t right_n[kBins];
+                Box acc = empty_box();
+                uint32_t cnt = 0;
+                for (int b = kBins - 1; b > 0; --b) {
+                    if (bin_n[b]) {
+                        grow(acc, bin_box[b]);
+                        cnt += bin_n[b];
+                    }
+                    right_area[b] = cnt ? half_area(acc) : 0.0;
+                    right_n[b] = cnt;
+                }
+                acc = empty_box();
+                cnt = 0;
+                for (int plane = 1; plane < kBins; ++plane) { // left = bins < plane
+                    if (bin_n[plane - 1]) {
+                        grow(acc, bin_box[plane - 1]);
+                        cnt += bin_n[plane - 1];
+                    }
+                    if (cnt == 0 || right_n[plane] == 0)
+                        continue;
+                    const double cost = half_area(acc) * cnt + right_area[plane] * right_n[plane];
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best_axis = a;
+                        best_plane = plane;
+                    }
+                }
+            }
+            if (best_axis >= 0 && std::isfinite(best_cost)) {
+                const int a = best_axis;
+                const double scale = (double)kBins / ((double)chi[a] - clo[a]);
+                auto left = [&](uint32_t item) {
+                    int b = (int)(((double)centre(item, a) - clo[a]) * scale);
+                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                    return b < best_plane;
+                };
+                const auto it = std::partition(items.begin() + begin, items.begin() + end, left);
+                const uint32_t mid = (uint32_t)(it - items.begin());
+                if (mid > begin && mid < end)
+                    return mid;
             }
         }
         int axis = 0;
@@ -116,6 +200,21 @@ struct Builder {
                                  const float cy = boxes[y].lo[axis] + boxes[y].hi[axis];
                                  return cx < cy;
                              });
+        return mid;
+    }
+
+    // emits the subtree over items[begin, end); returns its ref and box
+    uint32_t build(uint32_t begin, uint32_t end, uint32_t level, Box &box) {
+        box = bounds(begin, end);
+        const uint32_t n = end - begin;
+        if (n <= kLeafMax) {
+            const uint32_t ref = kBvhLeafBit | (n << 28) | (uint32_t)out.order.size();
+            for (uint32_t k = begin; k < end; ++k)
+                out.order.push_back(items[k]);
+            return ref;
+        }
+        out.depth = std::max(out.depth, level + 1);
+        const uint32_t mid = choose_split(begin, end, level);
         const uint32_t me = (uint32_t)(out.nodes.size() / 4);
         out.nodes.resize(out.nodes.size() + 4);
         Box lbox, rbox;

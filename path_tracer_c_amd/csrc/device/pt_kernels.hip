@@ -846,6 +846,170 @@ __global__ void __launch_bounds__(1024)
     count_wave(a.counters, rays, rays, done, iters, lane);
 }
 
+// ---------------------------------------------------------------------------
+// Kernel 2b: sample-queue mode for the BVH scan, with resumable walks.
+//
+// In pt_samplekernel a pass of the loop traces one whole segment per lane, so
+// a wave waits for its longest walk through the hierarchy, pass after pass.
+// Here a lane is in one of four states and the wave alternates between two
+// activities:
+//   walk     every lane in kWalk advances its walk by one quantum
+//            (bvh_walk_quantum, pt_trace.h);
+//   service  when enough lanes wait for something else (or none walks):
+//            lanes with a finished walk shade their hit, which yields the next
+//            ray or ends the path; ended paths unwind and store their sample;
+//            free lanes fetch a new (pixel, sample) task; every new ray starts
+//            its walk.
+// Tasks, output and the ordered sum (pt_sum_kernel) are those of
+// pt_samplekernel; only the order in which the device gets the work done
+// differs, so the image is the same.
+// ---------------------------------------------------------------------------
+template <bool kLds>
+__global__ void __launch_bounds__(1024)
+    pt_streamkernel(const LaunchArgs a, const F4 *__restrict__ scene_geom,
+                    const F4 *__restrict__ scene_tri,
+                    const F4 *__restrict__ scene_mat,
+                    const uint32_t *__restrict__ scene_meta,
+                    const uint32_t *__restrict__ scene_link,
+                    float4 *__restrict__ out,
+                    uint32_t *__restrict__ chunk_counter) {
+    extern __shared__ uint4 lds_dyn[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nthreads = blockDim.x;
+    const uint32_t lane = tid & 63u;
+    WorkgroupScene w = stage_scene<kLds>(a, lds_dyn, tid, nthreads);
+    if (!kLds) {
+        w.rec.geom = scene_geom;
+        w.rec.tri = scene_tri;
+        w.rec.mat = scene_mat;
+        w.rec.meta = scene_meta;
+        w.rec.link = scene_link;
+    }
+    const V3 sky = V3{a.scene.sky[0], a.scene.sky[1], a.scene.sky[2]};
+    const uint32_t npix = a.num_rows * a.framew;
+
+    uint32_t chunk_pos = 64u, chunk_sample = 0u, chunk_j0 = 0u;
+    uint32_t next_chunk = 0u, chunk_limit = 0u;
+    bool pool_dry = false;
+
+    enum : uint32_t { kFree = 0, kFresh = 1, kWalk = 2, kHit = 3, kParked = 4 };
+    uint32_t st = kFree;
+    uint32_t out_index = 0;
+    PathState p;
+    p.o = p.d = p.r = splat(0.0f);
+    p.depth = 0;
+    p.rng = 1u;
+    p.live = p.parked = false;
+    BvhWalk walk;
+    walk.inv = splat(0.0f);
+    walk.u = UnorderedBest{0.0f, -1, 0.0f, -1};
+    walk.cur = kBvhDone;
+    walk.sp = w.queue.stack;
+    walk.wr = w.queue.slot;
+    walk.min_index = 0u;
+    Hit hit = Hit{-1.0f, -1};
+    uint32_t rays = 0, iters = 0, done = 0;
+#ifdef PT_BVH_PROFILE
+    uint32_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#else
+    uint32_t *const prof = nullptr;
+#endif
+
+    for (;;) {
+        if (st == kWalk && bvh_walk_idle(w.queue, walk)) {
+            if (bvh_walk_finish(w.rec, w.queue, p.o, p.d, walk, hit))
+                st = kHit;
+        }
+        const unsigned long long walking = __ballot(st == kWalk);
+        const unsigned long long waiting =
+            __ballot(st == kHit || st == kParked || (st == kFree && !pool_dry));
+        if (walking == 0ull || (uint32_t)__popcll(waiting) >= a.settle_lanes) {
+            // ---- service -----------------------------------------------------------
+            PT_BVH_COUNT(6, st == kHit);
+            if (st == kHit) { // one recursion level of incident_light
+                advance_path<2>(w.rec, a, w.stack, nthreads, w.queue, sky, p, true, hit);
+                st = p.live ? kFresh : kParked;
+            }
+            if (st == kParked) {
+                const V3 sample = unwind_path(w.rec, w.stack, nthreads, p);
+                out[out_index] = make_float4(sample.x, sample.y, sample.z, 0.0f);
+                p.parked = false;
+                st = kFree;
+                ++done;
+            }
+            // refill free lanes from the wave's chunk (as pt_samplekernel does)
+            unsigned long long free_mask = __ballot(st == kFree);
+            while (free_mask != 0ull && !pool_dry) {
+                if (chunk_pos >= 64u) {
+                    if (next_chunk >= chunk_limit) {
+                        const int leader = __ffsll((long long)free_mask) - 1;
+                        uint32_t c = 0;
+                        if ((int)lane == leader)
+                            c = atomicAdd(chunk_counter, kChunkBatch);
+                        c = __shfl(c, leader, 64);
+                        if (c >= a.num_chunks) {
+                            pool_dry = true;
+                            break;
+                        }
+                        next_chunk = c;
+                        chunk_limit = c + kChunkBatch < a.num_chunks ? c + kChunkBatch
+                                                                     : a.num_chunks;
+                    }
+                    const uint32_t c = next_chunk++;
+                    chunk_sample = c / a.chunks_per_sample;
+                    chunk_j0 = (c - chunk_sample * a.chunks_per_sample) * 64u;
+                    chunk_pos = 0u;
+                }
+                const uint32_t avail = 64u - chunk_pos;
+                const uint32_t rank =
+                    (uint32_t)__popcll(free_mask & ((1ull << lane) - 1ull));
+                if (st == kFree && rank < avail) {
+                    const uint32_t j = chunk_j0 + chunk_pos + rank;
+                    if (j < npix) { // else: padding slot of the last chunk of a sample
+                        const PixelSite ps = pixel_site(a, j);
+                        st = kFresh;
+                        out_index = chunk_sample * a.npix_pad + j;
+                        p.o = splat(0.0f);
+                        p.d = ps.d0;
+                        p.r = splat(0.0f);
+                        p.depth = 0;
+                        p.rng = ptgpu_rng_seed(a.seed, ps.pixel,
+                                               a.sample_offset + chunk_sample);
+                        p.live = true;
+                        p.parked = false;
+                    }
+                }
+                const uint32_t wanted = (uint32_t)__popcll(free_mask);
+                chunk_pos += wanted < avail ? wanted : avail;
+                free_mask = __ballot(st == kFree);
+            }
+            // every new ray starts its walk (a poisoned one gets the
+            // reference's sequential scan at once, see closest_hit_bvh)
+            if (st == kFresh) {
+                ++rays;
+                if (ray_is_poisoned(p.o, p.d)) {
+                    hit = closest_hit(w.rec, p.o, p.d);
+                    st = kHit;
+                } else {
+                    bvh_walk_first(w.rec, w.queue, p.o, p.d, walk);
+                    st = kWalk;
+                }
+            }
+            if (__ballot(st != kFree) == 0ull)
+                break; // pool dry and every lane idle
+            continue;
+        }
+        ++iters;
+        bvh_walk_quantum(w.rec, w.queue, p.o, p.d, st == kWalk, a.walk_budget, walk, prof);
+    }
+#ifdef PT_BVH_PROFILE
+    if (lane == 0u)
+        for (int k = 0; k < 8; ++k)
+            atomicAdd(&g_bvh_profile[k], (unsigned long long)prof[k]);
+#endif
+    count_wave(a.counters, rays, rays, done, iters, lane);
+}
+
 // Adds the `spp` buffered samples of each pixel, in sample order, onto the
 // pixel's running sum (src/renderer.c:103-107), then stores either the
 // accumulator (float4: sums + sample count) or, on a frame's last pass, RGB8.
@@ -1034,11 +1198,11 @@ hipError_t launch_megakernel(const LaunchArgs &a, uint32_t block, bool tree,
                : launch_variant<false, false, 0>(a, grid, block, lds, stream);
 }
 
-template <bool kLds, int kScan>
+template <bool kLds, int kScan, bool kStream = false>
 static hipError_t launch_sample_variant(const LaunchArgs &a, uint32_t grid,
                                         uint32_t block, size_t lds_bytes,
                                         hipStream_t stream) {
-    auto kernel = pt_samplekernel<kLds, kScan>;
+    auto kernel = kStream ? pt_streamkernel<kLds> : pt_samplekernel<kLds, kScan>;
     if (lds_bytes > 64u * 1024u) {
         hipError_t e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(kernel),
@@ -1065,6 +1229,10 @@ hipError_t launch_samplekernel(const LaunchArgs &a, uint32_t block,
     if (grid == 0)
         grid = 1;
     const size_t lds = megakernel_lds_bytes(a, block, false);
+    if (a.screened == 2u && a.stream_walks)
+        return a.scene_in_lds
+                   ? launch_sample_variant<true, 2, true>(a, grid, block, lds, stream)
+                   : launch_sample_variant<false, 2, true>(a, grid, block, lds, stream);
     if (a.screened == 2u)
         return a.scene_in_lds
                    ? launch_sample_variant<true, 2>(a, grid, block, lds, stream)

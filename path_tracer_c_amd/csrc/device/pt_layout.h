@@ -103,6 +103,8 @@ struct LaunchArgs {
     uint32_t screened;     // scan form: 0 plain, 1 screened linear, 2 BVH (pt_trace.h)
     uint32_t settle_lanes; // parked lanes that trigger a settle stage (1..64)
     uint32_t share_primary; // pixel-owner kernel: scan the primary ray once per pixel
+    uint32_t stream_walks;  // sample queue + BVH scan: resumable walks (pt_streamkernel)
+    uint32_t walk_budget;   // ... inner-node steps per quantum
     uint32_t lanes_per_pixel; // pixel-owner kernel: 1, or 2..64 (power of two) lanes
                               // sharing a pixel's samples (small row sets)
     // sample-queue mode (pt_samplekernel / pt_sum_kernel)

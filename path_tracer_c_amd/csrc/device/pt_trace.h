@@ -251,6 +251,10 @@ __device__ __forceinline__ Hit closest_hit_screened(const SceneRecords &rec,
 // phases, as in the screened scan, early enough that `best` is known soon.
 // Triangles can never be degenerate (their test demands distance > 1e-6).
 // ---------------------------------------------------------------------------
+#ifndef PT_BVH_RESOLVE_AT
+#define PT_BVH_RESOLVE_AT 1u /* measured: 1 beats 0, 3 and 8 (C5 57 vs 58, 60, 62 ms) */
+#endif
+
 struct UnorderedBest {
     float best;     // smallest positive distance so far
     int best_idx;   // its object (lowest index among equals), -1: none
@@ -319,9 +323,6 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
     // a leaf adds at most kLeafMax = 4 entries, so resolving once 8 of the 12
     // slots are used would be enough; resolving earlier (PT_BVH_RESOLVE_AT
     // entries) makes `best` known sooner, and nodes beyond it are skipped
-#ifndef PT_BVH_RESOLVE_AT
-#define PT_BVH_RESOLVE_AT 1u /* measured: 1 beats 0, 3 and 8 (C5 57 vs 58, 60, 62 ms) */
-#endif
     uint32_t *const nearly_full = first + (PT_BVH_RESOLVE_AT) * q.stride;
 
     auto resolve = [&]() {
@@ -465,6 +466,176 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
             atomicAdd(&g_bvh_profile[k], (unsigned long long)prof[k]);
 #endif
     return h;
+}
+
+// ---------------------------------------------------------------------------
+// The same walk in resumable form, for the stream kernel (pt_kernels.hip).
+//
+// closest_hit_bvh() above runs a wave's 64 walks to completion together: the
+// wave pays for its longest walk, and measured on configuration 5 the average
+// lane takes part in only ~20 % of the inner-node steps its wave executes
+// (tools/bvh_profile.py).  Here the walk's state lives in a struct, one call
+// of bvh_walk_quantum() advances every walking lane by a bounded amount, and
+// between calls the kernel hands finished lanes their next ray.  Same boxes,
+// same screen, same exact tests, same accept rule: the hit is the same.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kBvhDone = 0xFFFFFFFFu; // not a valid ref: count field would be 7
+
+struct BvhWalk {
+    V3 inv;             // 1 / direction (approximate: boxes only)
+    UnorderedBest u;
+    uint32_t cur;       // ref being visited, kBvhDone: nothing left to visit
+    uint32_t *sp;       // next free entry of this lane's stack
+    uint32_t *wr;       // next free entry of this lane's candidate queue
+    uint32_t min_index; // only objects with index >= min_index count (second walk)
+};
+
+__device__ __forceinline__ bool ray_is_poisoned(V3 o, V3 d) {
+    const float probe = (fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) +
+                        (fabsf(d.x) + fabsf(d.y) + fabsf(d.z));
+    return !(probe < __builtin_inff());
+}
+
+// Starts (or, with min_index > 0, restarts) a walk.  Objects outside the
+// hierarchy are few or none and get their exact test right here.
+__device__ __forceinline__ void bvh_walk_begin(const SceneRecords &rec,
+                                               const ScreenQueue q, V3 o, V3 d,
+                                               uint32_t min_index, BvhWalk &w) {
+    w.min_index = min_index;
+    w.cur = rec.bvh_root;
+    w.sp = q.stack;
+    w.wr = q.slot;
+    for (uint32_t k = 0; k < rec.n_unbounded; ++k) {
+        const uint32_t idx = rec.bvh_unbounded[k];
+        if (idx >= min_index)
+            test_object_unordered(rec, o, d, idx, rec.geom[idx], w.u);
+    }
+}
+
+__device__ __forceinline__ void bvh_walk_first(const SceneRecords &rec,
+                                               const ScreenQueue q, V3 o, V3 d,
+                                               BvhWalk &w) {
+    w.inv = V3{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y),
+               __builtin_amdgcn_rcpf(d.z)};
+    w.u.best = __builtin_inff();
+    w.u.best_idx = -1;
+    w.u.deg_dist = 0.0f;
+    w.u.deg_idx = -1;
+    bvh_walk_begin(rec, q, o, d, 0u, w);
+}
+
+__device__ __forceinline__ bool bvh_walk_idle(const ScreenQueue q, const BvhWalk &w) {
+    return w.cur == kBvhDone && w.wr == q.slot;
+}
+
+// One quantum for the lanes with `mine`: up to `inner_budget` inner-node
+// steps (the loop also ends when no lane stands on an inner node), one leaf
+// for the lanes that stand on one, exact tests if some lane has queued
+// enough candidates or has nothing else left to do.
+__device__ __forceinline__ void bvh_walk_quantum(const SceneRecords &rec,
+                                                 const ScreenQueue q, V3 o, V3 d,
+                                                 bool mine, uint32_t inner_budget,
+                                                 BvhWalk &w, uint32_t *prof = nullptr) {
+    (void)prof;
+    auto crosses = [&](const F4 lo, const F4 hi, float &enter) {
+        const float x0 = (lo.x - o.x) * w.inv.x, x1 = (hi.x - o.x) * w.inv.x;
+        const float y0 = (lo.y - o.y) * w.inv.y, y1 = (hi.y - o.y) * w.inv.y;
+        const float z0 = (lo.z - o.z) * w.inv.z, z1 = (hi.z - o.z) * w.inv.z;
+        enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+        const float leave = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        const float slack = 1.0e-4f * (fabsf(enter) + fabsf(leave));
+        const bool missed = (enter == __builtin_inff()) | (leave == -__builtin_inff()) |
+                            (leave - enter < -slack) | (leave < -slack) |
+                            (enter - slack > w.u.best);
+        return !missed;
+    };
+    auto pop = [&]() {
+        if (w.sp != q.stack) {
+            w.sp -= q.stride;
+            w.cur = *w.sp;
+        } else {
+            w.cur = kBvhDone;
+        }
+    };
+    for (uint32_t step = 0; step < inner_budget; ++step) {
+        const bool inner = mine && w.cur != kBvhDone && !(w.cur & kLeafRef);
+        if (!__any(inner))
+            break;
+        PT_BVH_COUNT(0, inner);
+        if (inner) {
+            const F4 l_lo = rec.bvh_nodes[4u * w.cur + 0u];
+            const F4 l_hi = rec.bvh_nodes[4u * w.cur + 1u];
+            const F4 r_lo = rec.bvh_nodes[4u * w.cur + 2u];
+            const F4 r_hi = rec.bvh_nodes[4u * w.cur + 3u];
+            float l_enter, r_enter;
+            const bool go_l = crosses(l_lo, l_hi, l_enter);
+            const bool go_r = crosses(r_lo, r_hi, r_enter);
+            const uint32_t l_ref = __builtin_bit_cast(uint32_t, l_lo.w);
+            const uint32_t r_ref = __builtin_bit_cast(uint32_t, r_lo.w);
+            if (go_l & go_r) {
+                const bool r_first = r_enter < l_enter;
+                *w.sp = r_first ? l_ref : r_ref; // the farther child waits
+                w.sp += q.stride;
+                w.cur = r_first ? r_ref : l_ref;
+            } else if (go_l | go_r) {
+                w.cur = go_l ? l_ref : r_ref;
+            } else {
+                pop();
+            }
+        }
+    }
+    PT_BVH_COUNT(2, mine && w.cur != kBvhDone && (w.cur & kLeafRef));
+    if (mine && w.cur != kBvhDone && (w.cur & kLeafRef)) {
+        const uint32_t count = (w.cur >> 28) & 7u;
+        const uint32_t at = w.cur & 0x0FFFFFFFu;
+        for (uint32_t k = 0; k < count; ++k) {
+            const uint32_t idx = rec.bvh_order[at + k];
+            if (idx >= w.min_index && screen_keep(rec.geom[idx], o, d)) {
+                *w.wr = idx;
+                w.wr += q.stride;
+            }
+        }
+        pop();
+    }
+    uint32_t *const nearly_full = q.slot + (PT_BVH_RESOLVE_AT) * q.stride;
+    if (__any(mine && (w.wr > nearly_full || (w.cur == kBvhDone && w.wr != q.slot)))) {
+        for (uint32_t *rd = q.slot; __any(mine && rd < w.wr); rd += q.stride) {
+            PT_BVH_COUNT(4, mine && rd < w.wr);
+            if (mine && rd < w.wr) {
+                const uint32_t idx = *rd;
+                test_object_unordered(rec, o, d, idx, rec.geom[idx], w.u);
+            }
+        }
+        if (mine)
+            w.wr = q.slot;
+    }
+}
+
+// For a lane whose walk is idle: either restarts it as the second walk (the
+// answer lies beyond a degenerate candidate; returns false) or yields the hit.
+__device__ __forceinline__ bool bvh_walk_finish(const SceneRecords &rec,
+                                                const ScreenQueue q, V3 o, V3 d,
+                                                BvhWalk &w, Hit &h) {
+    const bool again = w.min_index == 0u && w.u.deg_idx >= 0 &&
+                       w.u.best_idx < w.u.deg_idx &&
+                       (uint32_t)w.u.deg_idx + 1u < rec.n_obj;
+    if (again) {
+        w.u.best = __builtin_inff();
+        w.u.best_idx = -1;
+        bvh_walk_begin(rec, q, o, d, (uint32_t)w.u.deg_idx + 1u, w);
+        return false;
+    }
+    if (w.u.best_idx >= 0 && w.u.best_idx > w.u.deg_idx) {
+        h.distance = w.u.best;
+        h.object = w.u.best_idx;
+    } else if (w.u.deg_idx >= 0) {
+        h.distance = w.u.deg_dist;
+        h.object = w.u.deg_idx;
+    } else {
+        h.distance = -1.0f;
+        h.object = -1;
+    }
+    return true;
 }
 
 struct Surface {

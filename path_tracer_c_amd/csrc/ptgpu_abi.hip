@@ -499,6 +499,23 @@ namespace {
 // settle stage about 265 (at 8 bounces) whatever the lane count.  Parking f
 // lanes for a pass wastes f/64 of a pass; settling costs one settle stage:
 // settle as soon as f * pass >= 64 * settle.
+// Stream kernel (sample queue + BVH scan): a service stage runs when this many
+// lanes of a wave wait for one, and a walk quantum takes this many inner-node
+// steps at most (PTGPU_WALK_BUDGET overrides, for tuning).
+constexpr uint32_t kStreamServiceLanes = 24;
+uint32_t stream_walk_budget() {
+    static const uint32_t budget = [] {
+        uint32_t v = 4u;
+        if (const char *e = std::getenv("PTGPU_WALK_BUDGET")) {
+            const long x = std::strtol(e, nullptr, 10);
+            if (x >= 1 && x <= 1024)
+                v = (uint32_t)x;
+        }
+        return v;
+    }();
+    return budget;
+}
+
 uint32_t auto_settle_lanes(const pt::SceneDesc &d) {
     const double pass = 80.0 * (double)d.n_obj + 400.0;
     double f = 64.0 * 265.0 / pass;
@@ -594,6 +611,8 @@ int prepare_launch(const ptgpu_scene *s, size_t framew, size_t frameh,
     if (p->lanes_per_pixel > 64u || (p->lanes_per_pixel & (p->lanes_per_pixel - 1u)) != 0u)
         return fail(PTGPU_ERR_INVALID, "lanes_per_pixel must be 0 or a power of two up to 64");
     a->lanes_per_pixel = 1u; // render_common decides
+    a->stream_walks = 0u;
+    a->walk_budget = 0u;
     if (p->settle_lanes > 64u)
         return fail(PTGPU_ERR_INVALID, "settle_lanes must be 0..64");
     a->settle_lanes = p->settle_lanes ? p->settle_lanes : auto_settle_lanes(s->desc);
@@ -953,6 +972,12 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         q.num_chunks = k * q.chunks_per_sample;
         q.chunk_counter = sc->chunk_counters + (sc->next_counter++ % kCounterRing);
         PT_TRY_HIP(hipMemsetAsync(q.chunk_counter, 0, sizeof(uint32_t), stream));
+        if (q.screened == 2u && !(p->flags & PTGPU_FLAG_WHOLE_WALKS)) {
+            // resumable walks: settle_lanes = lanes waiting before a service stage
+            q.stream_walks = 1u;
+            q.settle_lanes = p->settle_lanes ? p->settle_lanes : kStreamServiceLanes;
+            q.walk_budget = stream_walk_budget();
+        }
         hipError_t e = pt::launch_samplekernel(q, block, sc->max_waves, stream);
         if (e != hipSuccess)
             return fail_hip(e, "sample kernel launch");

@@ -17,13 +17,22 @@ w, h, spp = c['width'], c['height'], 16
 with pt.HostScene(c['scene']) as s, pt.DeviceScene(s) as d:
     st = torch.cuda.current_stream().cuda_stream
     img = torch.zeros((h, w, 3), dtype=torch.uint8, device='cuda')
-    for name, flags, k in (("owner k=1", 0x480, 1), ("owner k=64", 0x480, 64), ("queue", 0x500, 1)):
+    for name, flags, k in (("owner k=1", 0x480, 1), ("owner k=64", 0x480, 64), ("queue whole", 0xD00, 1),
+                           ("queue stream", 0x500, 1)):
         fn(out, 1)
+        pt.host.reset_stats()
         p = pt.make_params(spp=spp, max_bounces=c['max_bounces'], seed=1, flags=flags, lanes_per_pixel=k)
         d.render(img.data_ptr(), w, h, p, st); torch.cuda.synchronize()
         fn(out, 0)
         v = [float(x) for x in out]
+        stt = pt.host.read_stats()
         calls = v[7]
-        print(f"{name:11s} scans/wave-call: lanes {v[6]/calls:5.1f} | inner steps: {v[1]/calls:6.1f} wave-passes, "
+        if name == "queue stream":      # slots 6/7 count service stages there
+            print(f"{name:12s} per ray: inner {v[0]/stt.rays:5.1f} lane-steps, leaves {v[2]/stt.rays:4.2f}, exact tests {v[4]/stt.rays:4.2f} | "
+                  f"wave-passes per 64 rays: inner {64*v[1]/stt.rays:6.1f} (lane use {v[0]/(64*v[1]):.3f}), "
+                  f"leaf {64*v[3]/stt.rays:5.1f} ({v[2]/(64*v[3]):.3f}), resolve {64*v[5]/stt.rays:5.1f} ({v[4]/(64*v[5]):.3f}), "
+                  f"service {64*v[7]/stt.rays:5.1f} ({v[6]/(64*v[7]):.3f})", flush=True)
+            continue
+        print(f"{name:12s} scans/wave-call: lanes {v[6]/calls:5.1f} | inner steps: {v[1]/calls:6.1f} wave-passes, "
               f"lane use {v[0]/(64*v[1]):.3f} | leaf passes {v[3]/calls:5.1f}, lane use {v[2]/(64*v[3]):.3f} | "
               f"resolve passes {v[5]/calls:5.1f}, lane use {v[4]/(64*v[5]):.3f}", flush=True)
