@@ -728,8 +728,8 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         mode = kPixelOwner; // the branching kernel exists in pixel-owner form only
     const bool can_measure = a.counters != nullptr && !tree && total_spp >= 16 &&
                              npix * total_spp >= (1ull << 22);
-    if (mode < 0 && !can_measure)
-        mode = kPixelOwner;
+    if (mode < 0 && !can_measure) // (the BVH scan is at its best in queue form)
+        mode = (a.screened == 2u && !tree) ? kSampleQueue : kPixelOwner;
 
     // How many lanes share a pixel in the pixel-owner kernel (pt_kernels.hip,
     // run_paths_split).  More lanes = more, shorter waves: a small row set (a
@@ -811,18 +811,68 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
     a.accum = accum;
     uint32_t done_spp = 0;
 
+    // One pass of the sample-queue schedule: the next `want` samples (or as
+    // many as the sample buffer holds) of every pixel traced by persistent
+    // waves into the buffer, then added to the accumulator in sample order;
+    // the pass that completes the frame also writes RGB8.
+    const uint32_t npix_pad = (uint32_t)((npix + 63u) & ~(uint64_t)63u);
+    auto queue_pass = [&](uint32_t scan, uint32_t want) -> int {
+        uint64_t per_pass = scratch_budget_bytes() / ((uint64_t)npix_pad * 16u);
+        if (per_pass < 1)
+            per_pass = 1;
+        if ((uint64_t)npix_pad * per_pass > 0xFFFFFFFFull) // task ids are 32-bit
+            per_pass = 0xFFFFFFFFull / npix_pad;
+        const uint32_t k = (uint32_t)(want < per_pass ? want : per_pass);
+        // (sized for the frame's largest pass at once, not pass by pass)
+        const uint64_t k_frame = total_spp < per_pass ? total_spp : per_pass;
+        int grc = grow(&sc->samples, &sc->sample_bytes, (size_t)npix_pad * k_frame * 16u);
+        if (grc != PTGPU_OK)
+            return grc;
+        pt::LaunchArgs q = a;
+        q.screened = scan;
+        q.spp = k;
+        q.sample_offset = a.sample_offset + done_spp;
+        q.sample_buf = sc->samples;
+        q.npix_pad = npix_pad;
+        q.chunks_per_sample = npix_pad / 64u;
+        q.num_chunks = k * q.chunks_per_sample;
+        q.chunk_counter = sc->chunk_counters + (sc->next_counter++ % kCounterRing);
+        PT_TRY_HIP(hipMemsetAsync(q.chunk_counter, 0, sizeof(uint32_t), stream));
+        if (scan == 2u && !(p->flags & PTGPU_FLAG_WHOLE_WALKS)) {
+            // resumable walks: settle_lanes = lanes waiting before a service stage
+            q.stream_walks = 1u;
+            q.settle_lanes = p->settle_lanes ? p->settle_lanes : kStreamServiceLanes;
+            q.walk_budget = stream_walk_budget();
+        }
+        hipError_t e = pt::launch_samplekernel(q, block, sc->max_waves, stream);
+        if (e != hipSuccess)
+            return fail_hip(e, "sample kernel launch");
+        count_launch();
+        done_spp += k;
+        q.first_pass = accum_is_zero ? 1u : 0u;
+        accum_is_zero = false;
+        q.frame = (d_frame != nullptr && done_spp == total_spp) ? d_frame : nullptr;
+        e = pt::launch_sum(q, stream);
+        if (e != hipSuccess)
+            return fail_hip(e, "sum kernel launch");
+        return PTGPU_OK;
+    };
+
     // ---- first large render of this scene: measure, then choose ----------------
-    // Pilots = the first samples, rendered in pixel-owner form, 2 x 4 samples per
-    // candidate scan form (two candidates at most), each timed (they count: the pilots are part of the
-    // frame, and every scan form gives the same samples).  The fastest scan
-    // form is kept for this scene.  The pilots also yield rays per sample and
-    // the lane utilisation of pixel-owner waves.  The queue schedule recovers the idle
-    // lane-passes (utilisation -> ~0.99) but moves 32 bytes per sample through
-    // HBM (store + ordered re-read), worth ~480 lane-instructions of a chip
-    // that issues ~6e13 of them per second against ~4 TB/s.  Take the queue
-    // when the recovered work per sample is clearly (3x) more than that.
+    // Pilots = the first samples of the frame (they count: every scan form and
+    // schedule gives the same samples), rendered once per candidate scan form
+    // untimed (code-object load, clocks) and then in two interleaved timed
+    // rounds (A B A B), so that drift does not favour whoever runs second.  A
+    // linear scan is piloted in pixel-owner form; the BVH scan in the form it
+    // would really run in, sample-queue passes with resumable walks.  The
+    // fastest form is kept for this scene.  For a linear scan the pilots also
+    // yield rays per sample and the lane use of pixel-owner waves: the queue
+    // schedule recovers the idle lane-passes (use -> ~0.99) but moves 32 bytes
+    // per sample through HBM (store + ordered re-read), worth ~480
+    // lane-instructions of a chip that issues ~6e13 of them per second against
+    // ~4 TB/s.  Take the queue when the recovered work per sample is clearly
+    // (3x) more than that.
     if (mode < 0) {
-        // candidate scan forms for this object count (a forced form stays)
         uint32_t cand[3];
         int n_cand = 0;
         const bool scan_forced = (p->flags & (PTGPU_FLAG_SCAN_PLAIN | PTGPU_FLAG_SCAN_SCREENED |
@@ -831,89 +881,106 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         const bool has_bvh = a.scene.bvh_nodes != nullptr;
         if (scan_forced || n_obj < 4u) {
             cand[n_cand++] = a.screened;
-        } else if (n_obj < 128u || !has_bvh) {
+        } else if (n_obj < 64u || !has_bvh) {
             cand[n_cand++] = 0u;
             cand[n_cand++] = 1u;
-        } else if (n_obj < 8192u) {
+        } else if (n_obj < 4096u) {
             cand[n_cand++] = 1u;
             cand[n_cand++] = 2u;
         } else {
             cand[n_cand++] = 2u;
         }
-        // one untimed 1-sample launch per candidate first (code-object load,
-        // clocks), then two interleaved timed rounds (A B A B) of 3 samples per
-        // candidate, so that drift does not favour whoever runs second: 14
-        // samples in all; can_measure guarantees total_spp >= 16
+        // 1 + 2 * 3 samples per candidate: 14 in all at most; can_measure
+        // guarantees total_spp >= 16
         const uint32_t per_launch = 3u;
         const int rounds = 2;
-        pt::Counters before, after;
-        std::vector<hipEvent_t> ev((size_t)n_cand * rounds + 1, nullptr);
-        for (hipEvent_t &e : ev)
-            PT_TRY_HIP(hipEventCreate(&e));
-        PT_TRY_HIP(hipStreamSynchronize(stream));
-        rc = read_counters(a.counters, &before);
-        if (rc != PTGPU_OK)
-            return rc;
+        struct Tally {
+            double ms = 0.0, rays = 0.0, samples = 0.0, lane_passes = 0.0;
+        } tally[3];
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        PT_TRY_HIP(hipEventCreate(&ev[0]));
+        PT_TRY_HIP(hipEventCreate(&ev[1]));
+        struct DropEvents {
+            hipEvent_t *ev;
+            ~DropEvents() {
+                (void)hipEventDestroy(ev[0]);
+                (void)hipEventDestroy(ev[1]);
+            }
+        } drop_events{ev};
         if (accum_is_zero) {
             PT_TRY_HIP(hipMemsetAsync(accum, 0, (size_t)npix * 16u, stream));
             accum_is_zero = false;
         }
+        auto pilot = [&](uint32_t scan, uint32_t count, Tally *t) -> int {
+            pt::Counters before, after;
+            PT_TRY_HIP(hipStreamSynchronize(stream));
+            int prc = read_counters(a.counters, &before);
+            if (prc != PTGPU_OK)
+                return prc;
+            PT_TRY_HIP(hipEventRecord(ev[0], stream));
+            if (scan == 2u) {
+                const uint32_t target = done_spp + count;
+                while (done_spp < target) {
+                    prc = queue_pass(2u, target - done_spp);
+                    if (prc != PTGPU_OK)
+                        return prc;
+                }
+            } else {
+                pt::LaunchArgs q = a;
+                q.screened = scan;
+                q.spp = count;
+                q.sample_offset = a.sample_offset + done_spp;
+                hipError_t e = pt::launch_megakernel(q, block, false, stream);
+                if (e != hipSuccess)
+                    return fail_hip(e, "megakernel launch (pilot)");
+                count_launch();
+                done_spp += count;
+            }
+            PT_TRY_HIP(hipEventRecord(ev[1], stream));
+            PT_TRY_HIP(hipStreamSynchronize(stream));
+            prc = read_counters(a.counters, &after);
+            if (prc != PTGPU_OK)
+                return prc;
+            if (t != nullptr) {
+                float ms = 0.0f;
+                PT_TRY_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+                t->ms += ms;
+                t->rays += (double)(after.rays - before.rays);
+                t->samples += (double)(after.samples - before.samples);
+                t->lane_passes += 64.0 * (double)(after.wave_iters - before.wave_iters);
+            }
+            return PTGPU_OK;
+        };
         for (int i = 0; i < n_cand; ++i) { // warm-up, still real samples
-            pt::LaunchArgs q = a;
-            q.screened = cand[i];
-            q.spp = 1u;
-            q.sample_offset = a.sample_offset + done_spp;
-            hipError_t e = pt::launch_megakernel(q, block, false, stream);
-            if (e != hipSuccess)
-                return fail_hip(e, "megakernel launch (pilot warm-up)");
-            count_launch();
-            done_spp += 1u;
+            rc = pilot(cand[i], 1u, nullptr);
+            if (rc != PTGPU_OK)
+                return rc;
         }
-        PT_TRY_HIP(hipEventRecord(ev[0], stream));
         for (int k = 0; k < n_cand * rounds; ++k) {
-            pt::LaunchArgs q = a;
-            q.screened = cand[k % n_cand];
-            q.spp = per_launch;
-            q.sample_offset = a.sample_offset + done_spp;
-            hipError_t e = pt::launch_megakernel(q, block, false, stream);
-            if (e != hipSuccess)
-                return fail_hip(e, "megakernel launch (pilot)");
-            count_launch();
-            done_spp += per_launch;
-            PT_TRY_HIP(hipEventRecord(ev[(size_t)k + 1], stream));
+            rc = pilot(cand[k % n_cand], per_launch, &tally[k % n_cand]);
+            if (rc != PTGPU_OK)
+                return rc;
         }
-        PT_TRY_HIP(hipStreamSynchronize(stream));
-        float total_ms[3] = {0.0f, 0.0f, 0.0f};
-        for (int k = 0; k < n_cand * rounds; ++k) {
-            float ms = 0.0f;
-            PT_TRY_HIP(hipEventElapsedTime(&ms, ev[(size_t)k], ev[(size_t)k + 1]));
-            total_ms[k % n_cand] += ms;
-        }
-        for (hipEvent_t &e : ev)
-            (void)hipEventDestroy(e);
         int best = 0;
         for (int i = 1; i < n_cand; ++i)
-            if (total_ms[i] < total_ms[best])
+            if (tally[i].ms < tally[best].ms)
                 best = i;
         a.screened = cand[best];
         if (!scan_forced)
             s->scan_choice.store((int)cand[best]);
-        rc = read_counters(a.counters, &after);
-        if (rc != PTGPU_OK)
-            return rc;
-        const double rays = (double)(after.rays - before.rays);
-        const double samples = (double)(after.samples - before.samples);
-        const double lane_passes = 64.0 * (double)(after.wave_iters - before.wave_iters);
-        const double util = lane_passes > 0 && rays > 0 ? rays / lane_passes : 1.0;
-        const double rays_per_sample = samples > 0 ? rays / samples : 1.0;
-        const double instr_per_ray =
-            (a.screened == 2u ? 4500.0 / std::max(1.0, (double)n_obj)
-             : a.screened == 1u ? 16.0 : 80.0) * (double)n_obj + 400.0;
-        const double recovered = (1.0 / util - 1.0 / 0.99) * rays_per_sample * instr_per_ray;
-        // (3x, not 1x: 4-sample pilot launches under-state the utilisation a
-        // full-length launch reaches, because their tail weighs more)
-        mode = recovered > 3.0 * 480.0 ? kSampleQueue : kPixelOwner;
+        const Tally &t = tally[best];
+        const double rays_per_sample = t.samples > 0 ? t.rays / t.samples : 1.0;
         s->full_depth.store(rays_per_sample >= 0.93 * ((double)a.max_bounces + 1.0) ? 1 : 0);
+        if (a.screened == 2u) {
+            mode = kSampleQueue; // resumable walks exist in queue form only
+        } else {
+            const double util = t.lane_passes > 0 && t.rays > 0 ? t.rays / t.lane_passes : 1.0;
+            const double instr_per_ray = (a.screened == 1u ? 16.0 : 80.0) * (double)n_obj + 400.0;
+            const double recovered = (1.0 / util - 1.0 / 0.99) * rays_per_sample * instr_per_ray;
+            // (3x, not 1x: 3-sample pilot launches under-state the lane use a
+            // full-length launch reaches, because their tail weighs more)
+            mode = recovered > 3.0 * 480.0 ? kSampleQueue : kPixelOwner;
+        }
         s->queue_mode.store(mode);
         s->last_mode.store(mode);
         remember_choice(s);
@@ -948,47 +1015,10 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
     }
 
     // ---- sample-queue passes -----------------------------------------------------
-    const uint32_t npix_pad = (uint32_t)((npix + 63u) & ~(uint64_t)63u);
-    uint64_t per_pass = scratch_budget_bytes() / ((uint64_t)npix_pad * 16u);
-    if (per_pass < 1)
-        per_pass = 1;
-    if (per_pass > total_spp - done_spp)
-        per_pass = total_spp - done_spp;
-    if ((uint64_t)npix_pad * per_pass > 0xFFFFFFFFull) // task ids are 32-bit
-        per_pass = 0xFFFFFFFFull / npix_pad;
-    rc = grow(&sc->samples, &sc->sample_bytes, (size_t)npix_pad * per_pass * 16u);
-    if (rc != PTGPU_OK)
-        return rc;
     while (done_spp < total_spp) {
-        const uint32_t k = (uint32_t)(total_spp - done_spp < per_pass
-                                          ? total_spp - done_spp
-                                          : per_pass);
-        pt::LaunchArgs q = a;
-        q.spp = k;
-        q.sample_offset = a.sample_offset + done_spp;
-        q.sample_buf = sc->samples;
-        q.npix_pad = npix_pad;
-        q.chunks_per_sample = npix_pad / 64u;
-        q.num_chunks = k * q.chunks_per_sample;
-        q.chunk_counter = sc->chunk_counters + (sc->next_counter++ % kCounterRing);
-        PT_TRY_HIP(hipMemsetAsync(q.chunk_counter, 0, sizeof(uint32_t), stream));
-        if (q.screened == 2u && !(p->flags & PTGPU_FLAG_WHOLE_WALKS)) {
-            // resumable walks: settle_lanes = lanes waiting before a service stage
-            q.stream_walks = 1u;
-            q.settle_lanes = p->settle_lanes ? p->settle_lanes : kStreamServiceLanes;
-            q.walk_budget = stream_walk_budget();
-        }
-        hipError_t e = pt::launch_samplekernel(q, block, sc->max_waves, stream);
-        if (e != hipSuccess)
-            return fail_hip(e, "sample kernel launch");
-        count_launch();
-        done_spp += k;
-        q.first_pass = accum_is_zero ? 1u : 0u;
-        accum_is_zero = false;
-        q.frame = (d_frame != nullptr && done_spp == total_spp) ? d_frame : nullptr;
-        e = pt::launch_sum(q, stream);
-        if (e != hipSuccess)
-            return fail_hip(e, "sum kernel launch");
+        rc = queue_pass(a.screened, total_spp - done_spp);
+        if (rc != PTGPU_OK)
+            return rc;
     }
     return PTGPU_OK;
 }

@@ -224,8 +224,9 @@ def test_limits_and_bad_arguments_are_reported(gpu):
 
 
 @pytest.mark.parametrize("settle", [1, 5, 64])
-@pytest.mark.parametrize("flags", [0x10, 0x20, 0x60, 0x400, 0x540],
-                         ids=["plain", "screened", "lds+screened", "bvh", "bvh+lds+queue"])
+@pytest.mark.parametrize("flags", [0x10, 0x20, 0x60, 0x400, 0x480, 0x540, 0xD00],
+                         ids=["plain", "screened", "lds+screened", "bvh", "bvh+owner", "bvh+lds+queue",
+                              "bvh+queue+whole walks"])
 def test_scheduling_knobs_never_change_the_image(gpu, oracle, flags, settle):
     """settle_lanes and the scan variant are scheduling only."""
     for cfg, w, h, spp, b in [(0, 96, 60, 6, 4), (5, 64, 36, 4, 8), (2, 64, 36, 4, 8)]:
@@ -610,7 +611,9 @@ def test_randomised_scenes_match_the_oracle(gpu, oracle, branching):
             b = int(rng.integers(0, 11 if not branching else 5))
             flags = int(rng.choice([0, 0x40, 0x100, 0x20, 0x10, 0x140])) if not branching else int(rng.choice([0, 0x40]))
             if not branching and s.num_objects >= 64 and trial % 2:
-                flags |= 0x400                           # hierarchy scan
+                # hierarchy scan: default schedule, pixel owner, queue with
+                # resumable walks (+ LDS copy), queue with whole walks
+                flags = int(rng.choice([0x400, 0x480, 0x500, 0x540, 0xD00]))
             got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=trial, flags=flags)
             ref, _ = oracle.render_rows(s, w, h, spp=spp, max_bounces=b, seed=trial)
             assert np.array_equal(got, ref), (trial, w, h, spp, b, hex(flags), s.counts())
