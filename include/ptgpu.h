@@ -182,6 +182,10 @@ int ptgpu_scene_schedule(const ptgpu_scene *s);
 /* Scan form remembered for this scene (measured on the same occasion):
  * 0 not measured yet, 1 plain, 2 screened linear, 3 BVH. */
 int ptgpu_scene_scan(const ptgpu_scene *s);
+/* Size of the bounding-volume hierarchy built at upload (scenes of >= 64
+ * objects; not in the reference, see PTGPU_FLAG_SCAN_BVH): inner nodes and the
+ * longest chain of them.  Both 0 when the scene has none. */
+int ptgpu_scene_hierarchy(const ptgpu_scene *s, uint32_t *nodes, uint32_t *depth);
 
 /* -- rendering ------------------------------------------------------------- */
 /* Asynchronous: renders the row set of `p` of a framew x frameh image into

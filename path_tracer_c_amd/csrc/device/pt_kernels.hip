@@ -560,6 +560,7 @@ stage_scene(const LaunchArgs &a, uint4 *lds_dyn, uint32_t tid, uint32_t nthreads
     w.rec.n_nodes = a.scene.n_nodes;
     w.rec.n_unbounded = a.scene.n_unbounded;
     w.rec.bvh_root = a.scene.bvh_root;
+    w.rec.last_sphere = a.scene.last_sphere;
     w.stack = reinterpret_cast<uint16_t *>(lds_dyn + lds_used16) + tid;
     // the candidate queues of the screened scan sit behind the bounce stack
     // (2 * nthreads * (max_bounces + 1) bytes, rounded up to 16)
@@ -727,7 +728,7 @@ __global__ void __launch_bounds__(1024) pt_megakernel(const LaunchArgs a) {
 // sample_buf[t]; pt_sum_kernel then adds each pixel's samples in sample order,
 // which keeps the image bit-identical to pixel-owner mode.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kChunkBatch = 32; // chunks of 64 tasks reserved per atomic
+constexpr uint32_t kChunkBatchMax = 32; // chunks of 64 tasks reserved per atomic, at most
 
 // The scene arrays, the sample buffer and the chunk counter come in as separate
 // __restrict__ kernel arguments: this kernel stores to global memory inside
@@ -758,7 +759,7 @@ __global__ void __launch_bounds__(1024)
     const V3 sky = V3{a.scene.sky[0], a.scene.sky[1], a.scene.sky[2]};
     const uint32_t npix = a.num_rows * a.framew;
 
-    // wave-uniform cursor: a wave reserves kChunkBatch chunks with one atomic
+    // wave-uniform cursor: a wave reserves a.chunk_batch chunks with one atomic
     // (one global counter sustains only ~90 atomics per microsecond chip-wide;
     // per-chunk atomics made the counter, not the ALUs, the bottleneck) and
     // walks them one after the other
@@ -784,14 +785,14 @@ __global__ void __launch_bounds__(1024)
                     const int leader = __ffsll((long long)free_mask) - 1;
                     uint32_t c = 0;
                     if ((int)lane == leader)
-                        c = atomicAdd(chunk_counter, kChunkBatch);
+                        c = atomicAdd(chunk_counter, a.chunk_batch);
                     c = __shfl(c, leader, 64);
                     if (c >= a.num_chunks) {
                         pool_dry = true;
                         break;
                     }
                     next_chunk = c;
-                    chunk_limit = c + kChunkBatch < a.num_chunks ? c + kChunkBatch
+                    chunk_limit = c + a.chunk_batch < a.num_chunks ? c + a.chunk_batch
                                                                  : a.num_chunks;
                 }
                 const uint32_t c = next_chunk++;
@@ -910,7 +911,7 @@ __global__ void __launch_bounds__(1024)
     Hit hit = Hit{-1.0f, -1};
     uint32_t rays = 0, iters = 0, done = 0;
 #ifdef PT_BVH_PROFILE
-    uint32_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #else
     uint32_t *const prof = nullptr;
 #endif
@@ -919,6 +920,10 @@ __global__ void __launch_bounds__(1024)
         if (st == kWalk && bvh_walk_idle(w.queue, walk)) {
             if (bvh_walk_finish(w.rec, w.queue, p.o, p.d, walk, hit))
                 st = kHit;
+#ifdef PT_BVH_PROFILE
+            else
+                atomicAdd(&g_bvh_profile[8], 1ull);
+#endif
         }
         const unsigned long long walking = __ballot(st == kWalk);
         const unsigned long long waiting =
@@ -945,14 +950,14 @@ __global__ void __launch_bounds__(1024)
                         const int leader = __ffsll((long long)free_mask) - 1;
                         uint32_t c = 0;
                         if ((int)lane == leader)
-                            c = atomicAdd(chunk_counter, kChunkBatch);
+                            c = atomicAdd(chunk_counter, a.chunk_batch);
                         c = __shfl(c, leader, 64);
                         if (c >= a.num_chunks) {
                             pool_dry = true;
                             break;
                         }
                         next_chunk = c;
-                        chunk_limit = c + kChunkBatch < a.num_chunks ? c + kChunkBatch
+                        chunk_limit = c + a.chunk_batch < a.num_chunks ? c + a.chunk_batch
                                                                      : a.num_chunks;
                     }
                     const uint32_t c = next_chunk++;
@@ -988,7 +993,10 @@ __global__ void __launch_bounds__(1024)
             if (st == kFresh) {
                 ++rays;
                 if (ray_is_poisoned(p.o, p.d)) {
-                    hit = closest_hit(w.rec, p.o, p.d);
+#ifdef PT_BVH_PROFILE
+                    atomicAdd(&g_bvh_profile[9], 1ull);
+#endif
+                    hit = poisoned_hit(w.rec, p.o, p.d);
                     st = kHit;
                 } else {
                     bvh_walk_first(w.rec, w.queue, p.o, p.d, walk);
@@ -1004,7 +1012,7 @@ __global__ void __launch_bounds__(1024)
     }
 #ifdef PT_BVH_PROFILE
     if (lane == 0u)
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < 12; ++k)
             atomicAdd(&g_bvh_profile[k], (unsigned long long)prof[k]);
 #endif
     count_wave(a.counters, rays, rays, done, iters, lane);
@@ -1109,6 +1117,7 @@ __global__ void __launch_bounds__(256)
     rec.n_nodes = scene.n_nodes;
     rec.n_unbounded = scene.n_unbounded;
     rec.bvh_root = scene.bvh_root;
+    rec.last_sphere = scene.last_sphere;
     ScreenQueue queue;
     queue.slot = reinterpret_cast<uint32_t *>(lds_dyn) + threadIdx.x;
     queue.stride = blockDim.x;
@@ -1217,6 +1226,9 @@ static hipError_t launch_sample_variant(const LaunchArgs &a, uint32_t grid,
     return hipGetLastError();
 }
 
+static hipError_t launch_sample_dispatch(const LaunchArgs &a, uint32_t grid, uint32_t block,
+                                         size_t lds, hipStream_t stream);
+
 hipError_t launch_samplekernel(const LaunchArgs &a, uint32_t block,
                                uint32_t max_waves, hipStream_t stream) {
     if (a.num_chunks == 0)
@@ -1229,6 +1241,18 @@ hipError_t launch_samplekernel(const LaunchArgs &a, uint32_t block,
     if (grid == 0)
         grid = 1;
     const size_t lds = megakernel_lds_bytes(a, block, false);
+    // Chunks per reservation: 32 keep the one global counter out of the way
+    // (~90 atomics per microsecond is all it sustains), but a pass of few
+    // chunks must still be spread over all the waves, several reservations
+    // each, or most of the device idles while a few waves work them off.
+    LaunchArgs b = a;
+    uint64_t batch = a.num_chunks / ((uint64_t)grid * waves_per_block * 8u);
+    b.chunk_batch = (uint32_t)(batch < 1u ? 1u : (batch > kChunkBatchMax ? kChunkBatchMax : batch));
+    return launch_sample_dispatch(b, grid, block, lds, stream);
+}
+
+static hipError_t launch_sample_dispatch(const LaunchArgs &a, uint32_t grid, uint32_t block,
+                                         size_t lds, hipStream_t stream) {
     if (a.screened == 2u && a.stream_walks)
         return a.scene_in_lds
                    ? launch_sample_variant<true, 2, true>(a, grid, block, lds, stream)
@@ -1269,11 +1293,11 @@ extern "C" int ptgpu_debug_stamps(unsigned long long out[4], int reset) {
 #endif
 
 #ifdef PT_BVH_PROFILE
-extern "C" int ptgpu_debug_bvh_profile(unsigned long long out[8], int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_profile), sizeof(unsigned long long) * 8) != hipSuccess)
+extern "C" int ptgpu_debug_bvh_profile(unsigned long long out[12], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_profile), sizeof(unsigned long long) * 12) != hipSuccess)
         return -1;
     if (reset) {
-        unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long zero[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_profile), zero, sizeof zero) != hipSuccess)
             return -1;
     }

@@ -62,7 +62,7 @@ struct SceneDesc {
     uint32_t n_mat;
     uint32_t branching; // some material has 0 < transparency < 1
     float sky[3];
-    uint32_t pad;
+    uint32_t last_sphere; // highest index of a sphere, 0xFFFFFFFF: no sphere
 };
 
 // Bytes of the scene blob = LDS bytes its copy needs (16-byte records first,
@@ -103,6 +103,7 @@ struct LaunchArgs {
     uint32_t screened;     // scan form: 0 plain, 1 screened linear, 2 BVH (pt_trace.h)
     uint32_t settle_lanes; // parked lanes that trigger a settle stage (1..64)
     uint32_t share_primary; // pixel-owner kernel: scan the primary ray once per pixel
+    uint32_t chunk_batch;   // sample queue: chunks a wave reserves per atomic
     uint32_t stream_walks;  // sample queue + BVH scan: resumable walks (pt_streamkernel)
     uint32_t walk_budget;   // ... inner-node steps per quantum
     uint32_t lanes_per_pixel; // pixel-owner kernel: 1, or 2..64 (power of two) lanes

@@ -34,6 +34,7 @@ struct SceneRecords {
     uint32_t n_nodes;
     uint32_t n_unbounded;
     uint32_t bvh_root;
+    uint32_t last_sphere; // highest sphere index, 0xFFFFFFFF: none
 };
 
 PT_HD V3 xyz(const F4 &r) { return V3{r.x, r.y, r.z}; }
@@ -126,6 +127,34 @@ PT_HD Hit closest_hit(const SceneRecords &rec, V3 o, V3 d) {
     h.object = -1;
     for (uint32_t i = 0; i < rec.n_obj; ++i)
         test_object(rec, o, d, i, rec.geom[i], h);
+    return h;
+}
+
+// The closest hit of a ray with a NaN or infinite component, which no box test
+// can serve (src/ray.c's callers do produce such rays: a 0/0 root gives a NaN
+// distance, the hit point d * NaN + o is NaN, and every later ray of the path
+// starts there).  Working the reference's scan through for a ray with a NaN
+// component: glms_ray_sphere's ddp = dot(d, c - o) is NaN, so is the remedy
+// term, the discriminant and both roots; no comparison on the way rejects
+// (NaN < 0, a > b and a < 0 && b < 0 are all false), so EVERY sphere is found,
+// at distance NaN, and the accept rule keeps it (NaN >= closest is false).
+// glms_ray_triangle ends in `dist > eps` with dist NaN (or bails out on a tiny
+// finite determinant): never found.  The scan therefore returns the sphere
+// with the highest index, whatever the scene looks like -- which one exact test
+// reproduces, NaN bits included.  A scan of 64000 objects by one lane for each
+// of the up to MAX_BOUNCES later rays of such a path used to cost a whole
+// frame 150 ms.  Rays with an infinite but no NaN component (overflow) still
+// get the sequential scan.
+PT_HD Hit poisoned_hit(const SceneRecords &rec, V3 o, V3 d) {
+    const bool has_nan = (o.x != o.x) | (o.y != o.y) | (o.z != o.z) |
+                         (d.x != d.x) | (d.y != d.y) | (d.z != d.z);
+    if (!has_nan)
+        return closest_hit(rec, o, d);
+    Hit h;
+    h.distance = -1.0f;
+    h.object = -1;
+    if (rec.last_sphere != 0xFFFFFFFFu)
+        test_object(rec, o, d, rec.last_sphere, rec.geom[rec.last_sphere], h);
     return h;
 }
 
@@ -294,7 +323,7 @@ PT_HD void test_object_unordered(const SceneRecords &rec, V3 o, V3 d, uint32_t i
 // wave-passes of the three loops of the BVH scan, summed into device words no
 // kernel reads (tools/bvh_profile.py prints them).  Not in the shipped library.
 #ifdef PT_BVH_PROFILE
-__device__ unsigned long long g_bvh_profile[8];
+__device__ unsigned long long g_bvh_profile[12];
 #define PT_BVH_COUNT(slot, active)                                             \
     do {                                                                       \
         prof[slot] += (uint32_t)__popcll(__ballot(active));                    \
@@ -307,7 +336,7 @@ __device__ unsigned long long g_bvh_profile[8];
 __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3 d,
                                                const ScreenQueue q) {
 #ifdef PT_BVH_PROFILE
-    uint32_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     prof[6] = (uint32_t)__popcll(__ballot(true));
     prof[7] = 1u;
 #endif
@@ -458,11 +487,11 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
     }
     if (__any(poisoned)) {
         if (poisoned)
-            h = closest_hit(rec, o, d);
+            h = poisoned_hit(rec, o, d);
     }
 #ifdef PT_BVH_PROFILE
     if ((threadIdx.x & 63u) == 0u)
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < 12; ++k)
             atomicAdd(&g_bvh_profile[k], (unsigned long long)prof[k]);
 #endif
     return h;

@@ -440,7 +440,10 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
     h->desc.sky[0] = host->sky_color.x;
     h->desc.sky[1] = host->sky_color.y;
     h->desc.sky[2] = host->sky_color.z;
-    h->desc.pad = 0;
+    h->desc.last_sphere = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < n_obj; ++i)
+        if (host->objects[i].tag == 0)
+            h->desc.last_sphere = i;
     {
         std::lock_guard<std::mutex> guard(g_choice_mutex);
         auto known = g_choices.find(h->content_hash);
@@ -481,6 +484,14 @@ int ptgpu_scene_scan(const ptgpu_scene *s) {
     if (s == nullptr)
         return fail(PTGPU_ERR_INVALID, "scene is NULL");
     return s->scan_choice.load() + 1; // 0 not measured, 1 plain, 2 screened, 3 BVH
+}
+
+int ptgpu_scene_hierarchy(const ptgpu_scene *s, uint32_t *nodes, uint32_t *depth) {
+    if (s == nullptr || nodes == nullptr || depth == nullptr)
+        return fail(PTGPU_ERR_INVALID, "NULL argument");
+    *nodes = s->desc.bvh_nodes != nullptr ? s->desc.n_nodes : 0u;
+    *depth = s->desc.bvh_nodes != nullptr ? s->desc.bvh_depth : 0u;
+    return PTGPU_OK;
 }
 
 int ptgpu_scene_is_branching(const ptgpu_scene *s) {
@@ -612,6 +623,7 @@ int prepare_launch(const ptgpu_scene *s, size_t framew, size_t frameh,
         return fail(PTGPU_ERR_INVALID, "lanes_per_pixel must be 0 or a power of two up to 64");
     a->lanes_per_pixel = 1u; // render_common decides
     a->stream_walks = 0u;
+    a->chunk_batch = 1u; // the launcher decides
     a->walk_budget = 0u;
     if (p->settle_lanes > 64u)
         return fail(PTGPU_ERR_INVALID, "settle_lanes must be 0..64");

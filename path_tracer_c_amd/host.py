@@ -191,6 +191,13 @@ class DeviceScene:
         return ("by object count", "plain", "screened linear", "bvh")[
             check(lib().ptgpu_scene_scan(self.handle))]
 
+    @property
+    def hierarchy(self) -> tuple[int, int]:
+        """(inner nodes, depth) of the BVH built at upload; (0, 0) without one."""
+        nodes, depth = C.c_uint32(0), C.c_uint32(0)
+        check(lib().ptgpu_scene_hierarchy(self.handle, C.byref(nodes), C.byref(depth)))
+        return nodes.value, depth.value
+
     def render(self, d_frame_ptr: int, width: int, height: int, params: Params,
                stream: int = 0):
         check(lib().ptgpu_render_device(self.handle, C.c_void_p(d_frame_ptr),

@@ -128,6 +128,57 @@ def test_all_scan_forms_return_the_same_hits(gpu, oracle):
                 assert np.array_equal(bits(plain[2][fin]), bits(other[2][fin]))
 
 
+def test_nan_rays_hit_the_last_sphere_in_every_scan_form(gpu, oracle):
+    """A ray with a NaN component "finds" every sphere at distance NaN and no
+    triangle, so the reference's scan ends on the highest-index sphere.  The
+    BVH scan answers that with one exact test; plain scan and oracle walk the
+    whole array.  Mixed scene, triangles after the last sphere, a NaN-radius
+    sphere and an unbounded one among them."""
+    rng = np.random.default_rng(99)
+    nan, inf = np.nan, np.inf
+    with gpu.HostScene() as s:
+        s.set_sky(0.2, 0.3, 0.4)
+        mats = [s.add_material(tuple(rng.uniform(0.1, 0.9, 3)), roughness=float(rng.uniform(0, 1)))
+                for _ in range(40)]
+        for i in range(150):
+            c = rng.uniform(-6, 6, 3) + np.array([0, 0, 10])
+            if i % 5 == 0:
+                s.add_triangle(tuple(c), tuple(c + rng.uniform(-1, 1, 3)), tuple(c + rng.uniform(-1, 1, 3)),
+                               mats[i % 40])
+            else:
+                s.add_sphere(tuple(c), float(rng.uniform(0.2, 0.9)), mats[i % 40])
+        s.add_sphere((1, 1, 5), nan, mats[7])
+        s.add_sphere((inf, 0, 3), 1.0, mats[8])
+        s.add_sphere((2, -1, 6), 0.5, mats[39])             # the last sphere
+        for i in range(6):
+            c = rng.uniform(-3, 3, 3) + np.array([0, 0, 6])
+            s.add_triangle(tuple(c), tuple(c + rng.uniform(-1, 1, 3)), tuple(c + rng.uniform(-1, 1, 3)), mats[i])
+        rows_o, rows_d = [], []
+        for k in range(6):                                   # one NaN component at a time
+            for other in (0.0, 1.0, inf, -inf, 1e38):
+                v = np.array([0.1, -0.2, 0.97, 0.3, 0.4, 0.5], dtype=np.float64)
+                v[k] = nan
+                v[(k + 1) % 6] = other
+                rows_o.append(v[3:]); rows_d.append(v[:3])
+        rows_o.append([nan] * 3); rows_d.append([nan] * 3)
+        o = np.array(rows_o, dtype=f32); d = np.array(rows_d, dtype=f32)
+        ref = oracle.trace_rays(s, o, d)
+        assert np.isnan(ref[0]).all() and (ref[3] == mats[39]).all()
+        for flag in (0, gpu._abi.FLAG_SCAN_SCREENED, gpu._abi.FLAG_SCAN_BVH):
+            got = gpu.trace_rays(s, o, d, flag)
+            assert np.isnan(got[0]).all(), hex(flag)
+            assert np.array_equal(got[3], ref[3]), hex(flag)
+    with gpu.HostScene() as s:                               # no sphere at all: a NaN ray misses
+        m = s.add_material((0.5, 0.5, 0.5))
+        for i in range(70):
+            c = rng.uniform(-3, 3, 3) + np.array([0, 0, 6])
+            s.add_triangle(tuple(c), tuple(c + rng.uniform(-1, 1, 3)), tuple(c + rng.uniform(-1, 1, 3)), m)
+        o = np.array([[0, 0, 0], [nan, 0, 0]], dtype=f32); d = np.array([[nan, 0, 1], [0, 0, 1]], dtype=f32)
+        for flag in (0, gpu._abi.FLAG_SCAN_BVH):
+            got = gpu.trace_rays(s, o, d, flag)
+            assert (got[0] == -1).all(), hex(flag)
+
+
 def test_legacy_trace_ray_single_query(gpu, oracle):
     V = gpu._abi.Vec3
     with gpu.HostScene(0) as s:

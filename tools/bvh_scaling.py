@@ -32,15 +32,19 @@ def timeit(d, w, h, flags, spp=32):
     return e0.elapsed_time(e1), stt.rays, out.cpu().numpy()
 
 def main():
-  for n in [int(x) for x in (sys.argv[1:] or [250, 1000, 4000, 16000, 64000])]:
+  for n in [int(x) for x in (sys.argv[1:] or [64, 96, 128, 250, 1000, 4000, 16000, 64000, 256000])]:
       t0 = time.time()
       with scene(n) as s, pt.DeviceScene(s) as d:
           tb = time.time() - t0
           w, h = 960, 540
-          ms_l, rays, a = timeit(d, w, h, 0x120)
-          ms_b, _, b = timeit(d, w, h, 0x500)
-          assert (a == b).all()
-          print(f"n={n:6d}: linear-screened {ms_l:9.2f} ms ({rays/ms_l/1e6:7.3f} Gray/s)   bvh {ms_b:9.2f} ms ({rays/ms_b/1e6:7.3f} Gray/s)   ratio {ms_l/ms_b:5.2f}   (build+upload {tb:.2f}s)", flush=True)
+          spp = 32 if n <= 16000 else 8
+          ms_l, rays, a = timeit(d, w, h, 0x120, spp) if n <= 16000 else (float('nan'), 0, None)
+          ms_b, rays, b = timeit(d, w, h, 0x500, spp)
+          ms_w, _, c = timeit(d, w, h, 0xD00, spp)
+          assert a is None or (a == b).all()
+          assert (b == c).all()
+          print(f"n={n:6d}: linear-screened {ms_l:9.2f} ms ({rays/ms_l/1e6:7.3f} Gray/s)   bvh whole walks {ms_w:9.2f} ms   "
+                f"bvh resumable walks {ms_b:9.2f} ms ({rays/ms_b/1e6:7.3f} Gray/s)   linear/bvh {ms_l/ms_b:5.2f}   (build+upload {tb:.2f}s, nodes/depth {d.hierarchy})", flush=True)
 
 if __name__ == '__main__':
     main()
