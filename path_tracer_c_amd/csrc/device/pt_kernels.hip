@@ -582,11 +582,12 @@ struct PixelSite {
     V3 d0;
 };
 
-__device__ __forceinline__ PixelSite pixel_site(const LaunchArgs &a, uint64_t j) {
+// (j < num_rows * framew <= 2^32 - 1, checked by the host: 32-bit arithmetic)
+__device__ __forceinline__ PixelSite pixel_site(const LaunchArgs &a, uint32_t j) {
     PixelSite ps;
     const uint32_t W = a.framew;
-    const uint32_t lrow = (uint32_t)(j / W);
-    const uint32_t sx = (uint32_t)(j - (uint64_t)lrow * W);
+    const uint32_t lrow = j / W;
+    const uint32_t sx = j - lrow * W;
     uint32_t grow = a.row_begin + lrow;
     if (a.tile_rows != 0u) {
         const uint32_t tile = lrow / a.tile_rows;
@@ -675,7 +676,7 @@ __global__ void __launch_bounds__(1024) pt_megakernel(const LaunchArgs a) {
     const uint32_t q = (uint32_t)(t - j * k); // this lane's place among the pixel's k lanes
     const bool valid = j < npix;
     const bool owner = valid && q == 0u;  // holds the sum, reads and writes the pixel
-    const PixelSite ps = pixel_site(a, valid ? j : 0u);
+    const PixelSite ps = pixel_site(a, valid ? (uint32_t)j : 0u);
     const V3 sky = V3{a.scene.sky[0], a.scene.sky[1], a.scene.sky[2]};
 
     // ---- all samples of this pixel -----------------------------------------
@@ -1025,7 +1026,7 @@ __global__ void __launch_bounds__(256) pt_sum_kernel(const LaunchArgs a) {
     const uint32_t npix = a.num_rows * a.framew;
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = j < npix;
-    const PixelSite ps = pixel_site(a, valid ? j : 0u);
+    const PixelSite ps = pixel_site(a, valid ? (uint32_t)j : 0u);
     const float4 *buf = reinterpret_cast<const float4 *>(a.sample_buf);
     float4 *acc = reinterpret_cast<float4 *>(a.accum);
     // accum is addressed like the destination frame when it is the caller's

@@ -62,7 +62,7 @@ int fail_hip(hipError_t e, const char *where) {
 constexpr int kMaxDevices = 64;
 constexpr size_t kLdsBudget = 160u * 1024u; // one workgroup may own it all
 constexpr uint32_t kBvhMinObjects = 64;      // a hierarchy is built from here up
-constexpr uint32_t kBvhAutoObjects = 768;    // and used by default from here up
+constexpr uint32_t kBvhAutoObjects = 192;    // and used by default from here up
                                              // (measured: slower than the screened
                                              // linear scan at 250 objects, 1.2x
                                              // faster at 1000, 5.9x at 16000)
@@ -513,7 +513,7 @@ namespace {
 // Stream kernel (sample queue + BVH scan): a service stage runs when this many
 // lanes of a wave wait for one, and a walk quantum takes this many inner-node
 // steps at most (PTGPU_WALK_BUDGET overrides, for tuning).
-constexpr uint32_t kStreamServiceLanes = 24;
+constexpr uint32_t kStreamServiceLanes = 28;
 uint32_t stream_walk_budget() {
     static const uint32_t budget = [] {
         uint32_t v = 4u;

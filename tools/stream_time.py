@@ -15,8 +15,9 @@ with pt.HostScene(c['scene']) as s, pt.DeviceScene(s) as d:
     out = torch.zeros_like(ref)
     p = pt.make_params(spp=spp, max_bounces=c['max_bounces'], seed=1, flags=0x480, lanes_per_pixel=1)
     d.render(ref.data_ptr(), w, h, p, st); torch.cuda.synchronize()
-    for name, flags, settle in [("whole walks", 0xD00, 0)] + [(f"stream, service at {t}", 0x500, t) for t in (16, 24, 32)] + [(f"stream+LDS, service at {t}", 0x540, t) for t in (24, 32)]:
-        p = pt.make_params(spp=spp, max_bounces=c['max_bounces'], seed=1, flags=flags, settle_lanes=settle)
+    for name, flags, settle, block in [("whole walks", 0xD00, 0, 0)] + [(f"stream, service at {t}", 0x500, t, 0) for t in (16, 24, 32)] + \
+            [(f"stream, block {b}", 0x500, 24, b) for b in (128, 256)] + [(f"stream+LDS, block {b}", 0x540, 24, b) for b in (512, 1024)]:
+        p = pt.make_params(spp=spp, max_bounces=c['max_bounces'], seed=1, flags=flags, settle_lanes=settle, block_threads=block)
         d.render(out.data_ptr(), w, h, p, st); torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         pt.host.reset_stats()
