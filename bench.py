@@ -280,8 +280,12 @@ def main():
         rays_per_launch = rays_per_step / world / launches_per_step
         k_s = kernel_ms_avg * 1e-3 / launches_per_step
         achieved_tflops = rays_per_launch * fpr / k_s / 1e12
+        queue = dscene.schedule == "sample-queue"
+        bvh = dscene.scan == "bvh"
         if progressive:   # read + write one float4 per pixel per pass
             hbm_alg = 32.0 * shard.num_rows * w
+        elif queue:       # one float4 per sample stored, then read back in order
+            hbm_alg = 32.0 * samples / args.steps / world / launches_per_step
         else:             # 3 bytes per pixel, once
             hbm_alg = 3.0 * shard.num_rows * w
         line = {
@@ -311,7 +315,7 @@ def main():
                 "scan": dscene.scan,
             },
             "roofline": {
-                "kernel": "pt_samplekernel" if dscene.schedule == "sample-queue" else "pt_megakernel",
+                "kernel": ("pt_streamkernel" if bvh else "pt_samplekernel") if queue else "pt_megakernel",
                 "bound": "valu",
                 "achieved": achieved_tflops,
                 "peak": PEAK_FP32_VECTOR_TFLOPS,
@@ -323,6 +327,10 @@ def main():
                 "note": "FP32 vector ALU roof (SURVEY.md 8(d)): no MFMA on this path and HBM "
                         "is not binding; peak = FP32 vector figure of "
                         "MI355X_MICROARCH.md (256 CUs x 4 SIMD-32 x 2 FLOP x 2.4 GHz)",
+                **({"equivalent": "rays are priced at the reference's linear scan (src/ray.c:12-65: "
+                                  "every object tested); the hierarchy skips most of that arithmetic, "
+                                  "so `achieved`/`frac` here measure the speed-up over the reference's "
+                                  "algorithm at the ALU roof, not ALU utilisation"} if bvh else {}),
                 "traffic": read_profiled_traffic(args.workload),
                 "hbm": {"algorithmic_bytes_per_launch": hbm_alg,
                         "achieved": hbm_alg / k_s / 1e9, "peak": PEAK_HBM_GBS,
