@@ -134,7 +134,10 @@ typedef struct ptgpu_params {
                                many lanes of a wavefront must have finished a
                                sample before they settle it together.  0 =
                                chosen from the scene size; 1 = per-lane path
-                               regeneration; 64 = sample-synchronous waves */
+                               regeneration; 64 = sample-synchronous waves.
+                               In the sample queue with resumable BVH walks:
+                               lanes that must wait before the wave serves
+                               them (0 = 28) */
     uint32_t lanes_per_pixel; /* scheduling only, never changes the image:
                                lanes of a wavefront sharing one pixel's
                                samples in the pixel-owner schedule (the sum
@@ -162,8 +165,9 @@ typedef struct ptgpu_scene ptgpu_scene;
 /* The reference's compile-time settings: 16 spp, 4 bounces, fov pi/2. */
 int ptgpu_params_default(ptgpu_params *p);
 /* Defaults overridden by PTGPU_SPP, PTGPU_BOUNCES, PTGPU_SEED, PTGPU_FOV_DEG,
- * PTGPU_BLOCK, PTGPU_FLAGS, PTGPU_SETTLE; this is what the legacy entry points
- * use (they also honour PTGPU_DEVICES, see ptgpu_render_frame_multi). */
+ * PTGPU_BLOCK, PTGPU_FLAGS, PTGPU_SETTLE, PTGPU_LANES_PER_PIXEL; this is what
+ * the legacy entry points use (they also honour PTGPU_DEVICES, see
+ * ptgpu_render_frame_multi). */
 int ptgpu_params_from_env(ptgpu_params *p);
 
 /* -- devices --------------------------------------------------------------- */
