@@ -33,7 +33,10 @@
 
 namespace pt {
 
-constexpr uint32_t kLeafMax = 4;
+#ifndef PT_LEAF_MAX
+#define PT_LEAF_MAX 4
+#endif
+constexpr uint32_t kLeafMax = PT_LEAF_MAX;
 
 constexpr uint32_t kBvhLeafBit = 0x80000000u;
 
