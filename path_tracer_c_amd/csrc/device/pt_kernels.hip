@@ -510,6 +510,7 @@ struct WorkgroupScene {
     SceneRecords rec;
     uint16_t *stack;   // this lane's level-0 entry of the bounce stack
     ScreenQueue queue; // this lane's candidate queue (screened scan)
+    uint4 *tally;      // one record per wave of the workgroup (count_block)
 };
 
 // Stage the scene blob into LDS (kLds) or point at global memory, and carve
@@ -522,6 +523,8 @@ stage_scene(const LaunchArgs &a, uint4 *lds_dyn, uint32_t tid, uint32_t nthreads
     const uint32_t n_tri = a.scene.n_tri;
     const uint32_t n_mat = a.scene.n_mat;
     w.rec.n_obj = n_obj;
+    w.tally = lds_dyn;
+    lds_dyn += nthreads / 64u; // everything else sits behind the tally records
     uint32_t lds_used16 = 0;
     if (kLds) {
         const uint32_t blob16 =
@@ -604,19 +607,30 @@ __device__ __forceinline__ PixelSite pixel_site(const LaunchArgs &a, uint32_t j)
     return ps;
 }
 
-// result * (1.0f / NUM_SAMPLES * 255.0f), truncated (src/renderer.c:108-114),
-// stored as coalesced dwords when the wave's 64 pixels are 192 contiguous,
-// 4-byte aligned bytes, else as single bytes.
-__device__ __forceinline__ void store_rgb8(uint8_t *frame, V3 sum, float samples,
-                                           uint64_t out_pixel, bool valid,
-                                           uint32_t lane) {
+// result * (1.0f / NUM_SAMPLES * 255.0f), truncated (src/renderer.c:108-114).
+__device__ __forceinline__ uint32_t pack_rgb8(V3 sum, float samples) {
     const float scale = 1.0f / samples * 255.0f;
     const V3 px = sum * scale;
     const uint32_t r8 = (uint32_t)(uint8_t)px.x;
     const uint32_t g8 = (uint32_t)(uint8_t)px.y;
     const uint32_t b8 = (uint32_t)(uint8_t)px.z;
-    const uint32_t packed = r8 | (g8 << 8) | (b8 << 16);
+    return r8 | (g8 << 8) | (b8 << 16);
+}
 
+__device__ __forceinline__ void store_rgb8_bytes(uint8_t *frame, uint32_t packed,
+                                                 uint64_t out_pixel) {
+    uint8_t *dst = frame + 3u * out_pixel;
+    dst[0] = (uint8_t)packed;
+    dst[1] = (uint8_t)(packed >> 8);
+    dst[2] = (uint8_t)(packed >> 16);
+}
+
+// One pixel per lane: stored as coalesced dwords when the wave's 64 pixels
+// are 192 contiguous, 4-byte aligned bytes, else as single bytes.
+__device__ __forceinline__ void store_rgb8(uint8_t *frame, V3 sum, float samples,
+                                           uint64_t out_pixel, bool valid,
+                                           uint32_t lane) {
+    const uint32_t packed = pack_rgb8(sum, samples);
     const uint64_t first = __shfl(out_pixel, 0, 64);
     const bool wave_dense =
         __all(valid && out_pixel == first + lane) &&
@@ -634,28 +648,97 @@ __device__ __forceinline__ void store_rgb8(uint8_t *frame, V3 sum, float samples
             dst[lane] = (uint32_t)(both >> sh);
         }
     } else if (valid) {
-        uint8_t *dst = frame + 3u * out_pixel;
-        dst[0] = (uint8_t)r8;
-        dst[1] = (uint8_t)g8;
-        dst[2] = (uint8_t)b8;
+        store_rgb8_bytes(frame, packed, out_pixel);
     }
 }
 
-__device__ __forceinline__ void count_wave(Counters *c, uint32_t rays,
-                                           uint32_t scans, uint32_t samples,
-                                           uint32_t iters, uint32_t lane) {
-    if (c == nullptr)
+// k lanes per pixel: a wave holds only 64 / k pixels (192 / k bytes), and a
+// store of part of a cache line leaves the XCD's L2 as a masked write of its
+// own (measured: 45 MB of write traffic for the 6.2 MB C2 frame).  So the
+// workgroup (64 * k work-items when the host can arrange it) gathers its
+// pixels in LDS -- each wave in its own 128 bytes of the bounce stack's first
+// row, free by now -- and its first wave stores them as whole dwords, 192
+// contiguous bytes per 64 pixels.  `owner`: this lane holds pixel
+// block_first + (tid / k).  All work-items of the workgroup must call this.
+__device__ __forceinline__ void
+store_rgb8_block(const LaunchArgs &a, uint16_t *stack_row, V3 sum, float samples,
+                 uint64_t out_pixel, bool owner, uint32_t tid, uint32_t nthreads,
+                 uint32_t k, uint64_t first_local_pixel, uint64_t npix) {
+    const uint32_t packed = pack_rgb8(sum, samples);
+    const uint32_t block_pixels = nthreads / k;
+    const uint32_t wave_pixels = 64u / k;
+    // contiguous in the destination: rows follow each other (no tile gaps) and
+    // the workgroup's pixels all exist
+    const bool contiguous = (a.compact != 0u || a.tile_rows == 0u) &&
+                            first_local_pixel + block_pixels <= npix;
+    const uint64_t first_out = out_pixel - (tid / k); // of the workgroup, if contiguous
+    const uint64_t block_first_out = __shfl(first_out, 0, 64);
+    const bool dense = contiguous && (block_pixels & 3u) == 0u &&
+                       ((reinterpret_cast<uintptr_t>(a.frame + 3u * block_first_out) & 3u) == 0u);
+    if (!dense) { // wave-uniform (same for the whole workgroup, in fact)
+        if (owner)
+            store_rgb8_bytes(a.frame, packed, out_pixel);
+        return;
+    }
+    uint32_t *stage = reinterpret_cast<uint32_t *>(stack_row - tid); // workgroup's row
+    if ((tid & (k - 1u)) == 0u) {
+        const uint32_t p = tid / k; // pixel of the workgroup
+        stage[(p / wave_pixels) * 32u + p % wave_pixels] = packed;
+    }
+    __syncthreads();
+    // 3 * block_pixels / 4 dwords, stored by the first work-items
+    const uint32_t dwords = 3u * block_pixels / 4u;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(a.frame + 3u * block_first_out);
+    for (uint32_t j = tid; j < dwords; j += nthreads) {
+        const uint32_t p0 = (4u * j) / 3u;
+        const uint32_t sh = 8u * (4u * j - 3u * p0);
+        const uint32_t p1 = p0 + 1u < block_pixels ? p0 + 1u : p0;
+        const uint32_t lo = stage[(p0 / wave_pixels) * 32u + p0 % wave_pixels];
+        const uint32_t hi = stage[(p1 / wave_pixels) * 32u + p1 % wave_pixels];
+        const uint64_t both = (uint64_t)lo | ((uint64_t)hi << 24);
+        dst[j] = (uint32_t)(both >> sh);
+    }
+}
+
+// Adds a workgroup's totals to the statistics.  Device-scope atomics are
+// performed memory-side on this chip (the XCDs' L2s do not see each other) and
+// cost a 32-byte fabric write each: four per wave were 33 MB per C2 frame,
+// five times the frame itself.  So the waves of a workgroup first add up in
+// LDS, and the four counters -- adjacent words of one 32-byte record -- are
+// then updated by four lanes of ONE atomic instruction, which travels as one
+// request.  All work-items of the workgroup must call this (it may barrier).
+__device__ __forceinline__ void count_block(Counters *c, uint4 *tally, uint32_t rays,
+                                            uint32_t scans, uint32_t samples,
+                                            uint32_t iters, uint32_t tid,
+                                            uint32_t nthreads) {
+    if (c == nullptr) // (wave-uniform, in fact launch-uniform)
         return;
     c += blockIdx.x & (kCounterShards - 1u);
-    const uint32_t wrays = wave_sum(rays);
-    const uint32_t wscans = wave_sum(scans);
-    const uint32_t wsamples = wave_sum(samples);
-    const uint32_t witers = wave_max(iters);
-    if (lane == 0u) {
-        atomicAdd(&c->rays, (unsigned long long)wrays);
-        atomicAdd(&c->scans, (unsigned long long)wscans);
-        atomicAdd(&c->samples, (unsigned long long)wsamples);
-        atomicAdd(&c->wave_iters, (unsigned long long)witers);
+    const uint32_t lane = tid & 63u;
+    uint4 mine = make_uint4(wave_sum(rays), wave_sum(scans), wave_sum(samples), wave_max(iters));
+    if (nthreads > 64u) {
+        if (lane == 0u)
+            tally[tid / 64u] = mine;
+        __syncthreads();
+        if (tid >= 64u)
+            return;
+        mine = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t wv = 0; wv < nthreads / 64u; ++wv) {
+            const uint4 t = tally[wv];
+            mine.x += t.x;
+            mine.y += t.y;
+            mine.z += t.z;
+            mine.w += t.w;
+        }
+    }
+    // Counters = { rays, samples, wave_iters, scans }: lane i adds word i
+    static_assert(offsetof(Counters, rays) == 0 && offsetof(Counters, samples) == 8 &&
+                      offsetof(Counters, wave_iters) == 16 && offsetof(Counters, scans) == 24,
+                  "count_block addresses the counters as four adjacent words");
+    if (lane < 4u) {
+        const uint32_t v = lane == 0u ? mine.x : lane == 1u ? mine.z : lane == 2u ? mine.w : mine.y;
+        // rays, samples, wave_iters, scans
+        atomicAdd(reinterpret_cast<unsigned long long *>(c) + lane, (unsigned long long)v);
     }
 }
 
@@ -709,9 +792,13 @@ __global__ void __launch_bounds__(1024) pt_megakernel(const LaunchArgs a) {
             reinterpret_cast<float4 *>(a.accum)[acc_at] =
                 make_float4(sum.x, sum.y, sum.z, had + (float)a.spp);
     } else {
-        store_rgb8(a.frame, sum, (float)a.spp, ps.out_pixel, owner, tid & 63u);
+        if (kTree || k == 1u)
+            store_rgb8(a.frame, sum, (float)a.spp, ps.out_pixel, owner, tid & 63u);
+        else
+            store_rgb8_block(a, w.stack, sum, (float)a.spp, ps.out_pixel, owner, tid, nthreads, k,
+                             (uint64_t)blockIdx.x * (nthreads / k), npix);
     }
-    count_wave(a.counters, rays, scans, samples_done, iters, tid & 63u);
+    count_block(a.counters, w.tally, rays, scans, samples_done, iters, tid, nthreads);
 }
 
 // ---------------------------------------------------------------------------
@@ -845,7 +932,7 @@ __global__ void __launch_bounds__(1024)
             }
         }
     }
-    count_wave(a.counters, rays, rays, done, iters, lane);
+    count_block(a.counters, w.tally, rays, rays, done, iters, tid, nthreads);
 }
 
 // ---------------------------------------------------------------------------
@@ -1016,7 +1103,7 @@ __global__ void __launch_bounds__(1024)
         for (int k = 0; k < 12; ++k)
             atomicAdd(&g_bvh_profile[k], (unsigned long long)prof[k]);
 #endif
-    count_wave(a.counters, rays, rays, done, iters, lane);
+    count_block(a.counters, w.tally, rays, rays, done, iters, tid, nthreads);
 }
 
 // Adds the `spp` buffered samples of each pixel, in sample order, onto the
@@ -1167,7 +1254,7 @@ static hipError_t launch_variant(const LaunchArgs &a, uint32_t grid,
 }
 
 size_t megakernel_lds_bytes(const LaunchArgs &a, uint32_t block, bool tree) {
-    size_t bytes = 0;
+    size_t bytes = (size_t)16 * (block / 64u); // tally records (count_block)
     if (a.scene_in_lds) {
         bytes += scene_lds_bytes(a.scene.n_obj, a.scene.n_tri, a.scene.n_mat);
         if (a.screened == 2u && !tree)

@@ -83,8 +83,10 @@ struct alignas(64) Counters {
     unsigned long long rays;
     unsigned long long samples;
     unsigned long long wave_iters;
-    unsigned long long launches; // unused on the device (counted on the host)
     unsigned long long scans;    // closest-hit scans executed (<= rays)
+    // (the four above are one 32-byte record: count_block updates them with
+    // one atomic instruction)
+    unsigned long long launches; // unused on the device (counted on the host)
 };
 constexpr uint32_t kCounterShards = 256;
 

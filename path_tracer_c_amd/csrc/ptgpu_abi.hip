@@ -753,9 +753,29 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
     // takes to reach ~24 rounds of waves when the scene is known to run its
     // paths to the bounce limit, and otherwise only as many as fit into
     // wave slots that would stay empty.
+    uint32_t owner_block = block; // workgroup size of pixel-owner launches
     auto choose_lanes = [&](bool may_fall_back_to_queue) {
         if (mode != kPixelOwner || tree)
             return;
+        // On leaving: with k lanes per pixel, workgroups of up to 256
+        // work-items, so that a workgroup's pixels leave as one run of whole
+        // dwords (store_rgb8_block; 192 bytes for k <= 4) and its statistics as
+        // one atomic.  Larger workgroups cost time (C2, k = 8: 62.1 ms at
+        // 64..256, 66.4 at 512).
+        struct FitBlock {
+            pt::LaunchArgs &a;
+            const ptgpu_params *p;
+            uint32_t block, &owner_block;
+            ~FitBlock() {
+                owner_block = block;
+                uint32_t want = 64u * a.lanes_per_pixel;
+                if (want > 256u)
+                    want = 256u;
+                if (a.lanes_per_pixel > 1u && p->block_threads == 0u && want > block &&
+                    pt::megakernel_lds_bytes(a, want, false) <= 64u * 1024u)
+                    owner_block = want;
+            }
+        } fit_block{a, p, block, owner_block};
         DeviceScratch *probe = nullptr;
         if (p->lanes_per_pixel != 0u) {
             a.lanes_per_pixel = p->lanes_per_pixel;
@@ -786,7 +806,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         a.frame = d_frame;  // exactly one of the two is non-null
         a.accum = d_accum;
         a.accum_local = 0;
-        hipError_t e = pt::launch_megakernel(a, block, tree, stream);
+        hipError_t e = pt::launch_megakernel(a, owner_block, tree, stream);
         if (e != hipSuccess)
             return fail_hip(e, "megakernel launch");
         count_launch();
@@ -942,7 +962,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
                 q.screened = scan;
                 q.spp = count;
                 q.sample_offset = a.sample_offset + done_spp;
-                hipError_t e = pt::launch_megakernel(q, block, false, stream);
+                hipError_t e = pt::launch_megakernel(q, owner_block, false, stream);
                 if (e != hipSuccess)
                     return fail_hip(e, "megakernel launch (pilot)");
                 count_launch();
@@ -1009,7 +1029,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
             pt::LaunchArgs q = a;
             q.spp = total_spp - done_spp;
             q.sample_offset = a.sample_offset + done_spp;
-            hipError_t e = pt::launch_megakernel(q, block, tree, stream);
+            hipError_t e = pt::launch_megakernel(q, owner_block, tree, stream);
             if (e != hipSuccess)
                 return fail_hip(e, "megakernel launch (accumulate)");
             count_launch();

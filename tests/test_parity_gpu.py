@@ -303,6 +303,32 @@ def test_lanes_per_pixel_never_changes_the_image(gpu, oracle, k):
         assert np.array_equal(got, ref), (cfg, k)
 
 
+@pytest.mark.parametrize("k,block", [(2, 64), (4, 256), (8, 128), (8, 512), (16, 1024), (16, 64), (32, 256)])
+def test_lanes_per_pixel_store_paths(gpu, oracle, torch_cuda, k, block):
+    """RGB8 stores with several lanes per pixel, device frames: whole frames
+    whose width makes workgroups straddle rows, row subsets, interleaved tiles
+    with and without compact rows (tile gaps make a workgroup's pixels
+    non-contiguous in the destination)."""
+    torch = torch_cuda
+    w, h, spp, b = 76, 41, 5, 5
+    with gpu.HostScene(2) as s, gpu.DeviceScene(s) as d:
+        ref, _ = oracle.render_rows(s, w, h, spp=spp, max_bounces=b, seed=8)
+        kw = dict(spp=spp, max_bounces=b, seed=8, lanes_per_pixel=k, block_threads=block)
+        assert np.array_equal(render_device(gpu, torch, d, w, h, flags=0x80, **kw), ref)
+        part = render_device(gpu, torch, d, w, h, flags=0x80, row_begin=3, num_rows=17, **kw)
+        assert np.array_equal(part[3:20], ref[3:20]) and not part[:3].any() and not part[20:].any()
+        sh = gpu.tiles.shard_rows(h, 3, 1, 4)
+        rows = sh.global_rows()
+        tiled = render_device(gpu, torch, d, w, h, flags=0x80, row_begin=sh.row_begin,
+                              num_rows=sh.num_rows, tile_rows=4, tile_stride=3, **kw)
+        assert np.array_equal(tiled[rows], ref[rows])
+        mask = np.ones(h, bool); mask[rows] = False
+        assert not tiled[mask].any()
+        compact = render_device(gpu, torch, d, w, h, flags=0x81, row_begin=sh.row_begin,
+                                num_rows=sh.num_rows, tile_rows=4, tile_stride=3, **kw)
+        assert compact.shape[0] == sh.num_rows and np.array_equal(compact, ref[rows])
+
+
 def test_lanes_per_pixel_progressive_and_stats(gpu):
     """Accumulator passes with several lanes per pixel equal the one-lane
     passes bit for bit, and the counters still count every sample once."""
