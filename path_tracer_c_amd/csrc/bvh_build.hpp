@@ -234,8 +234,11 @@ struct Builder {
 } // namespace bvh_detail
 
 // `geom` = the uploaded geometry records: (centre, +r^2) for spheres,
-// (bounding centre, -r^2) for triangles.
-inline BvhHost build_bvh(const F4 *geom, uint32_t n_obj) {
+// (bounding centre, -r^2) for triangles.  `corners` (optional): for object i
+// with corners[6 i] <= corners[6 i + 3] its own axis-aligned extent
+// {lo.xyz, hi.xyz} -- a triangle's vertices span much less than its bounding
+// sphere -- which is then padded and intersected with the sphere's box.
+inline BvhHost build_bvh(const F4 *geom, uint32_t n_obj, const float *corners = nullptr) {
     using bvh_detail::Box;
     BvhHost out;
     std::vector<Box> boxes;
@@ -253,6 +256,28 @@ inline BvhHost build_bvh(const F4 *geom, uint32_t n_obj) {
             b.lo[a] = std::nextafter((float)(c[a] - pad), -std::numeric_limits<float>::infinity());
             b.hi[a] = std::nextafter((float)(c[a] + pad), std::numeric_limits<float>::infinity());
             finite = std::isfinite(c[a]) && std::isfinite(b.lo[a]) && std::isfinite(b.hi[a]);
+        }
+        if (finite && corners != nullptr && corners[6 * (size_t)i] <= corners[6 * (size_t)i + 3]) {
+            // the exact test accepts points of the triangle only (up to its own
+            // rounding, ~1e-6 of the coordinates): pad by 1e-3 of the largest
+            // extent plus 1e-5 of the coordinates' magnitude
+            const float *e = corners + 6 * (size_t)i;
+            double span = 0.0, mag = 0.0;
+            bool ok = true;
+            for (int a = 0; a < 3; ++a) {
+                ok = ok && std::isfinite(e[a]) && std::isfinite(e[a + 3]) && e[a] <= e[a + 3];
+                span = std::max(span, (double)e[a + 3] - e[a]);
+                mag = std::max(mag, std::max(std::fabs((double)e[a]), std::fabs((double)e[a + 3])));
+            }
+            if (ok) {
+                const double pad = 1e-3 * span + 1e-5 * mag + 1e-30;
+                for (int a = 0; a < 3; ++a) {
+                    const float lo = std::nextafter((float)(e[a] - pad), -std::numeric_limits<float>::infinity());
+                    const float hi = std::nextafter((float)(e[a + 3] + pad), std::numeric_limits<float>::infinity());
+                    b.lo[a] = std::max(b.lo[a], lo); // never larger than the sphere's box
+                    b.hi[a] = std::min(b.hi[a], hi);
+                }
+            }
         }
         if (!finite) {
             out.unbounded.push_back(i);

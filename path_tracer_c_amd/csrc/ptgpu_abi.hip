@@ -405,7 +405,28 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
     h->desc.bvh_root = pt::kBvhLeafBit;
     h->desc.bvh_depth = 0;
     if (n_obj >= kBvhMinObjects) {
-        const pt::BvhHost bvh = pt::build_bvh(geom, n_obj);
+        // triangles: their vertices' extent (much tighter than the box of the
+        // bounding sphere the screen uses); spheres: none (lo > hi)
+        std::vector<float> corners((size_t)6 * n_obj);
+        for (uint32_t i = 0; i < n_obj; ++i) {
+            float *e = &corners[(size_t)6 * i];
+            e[0] = 1.0f;
+            e[3] = 0.0f;
+            const shape &o = host->objects[i];
+            if (o.tag != 1)
+                continue;
+            const vec3s v[3] = {o.triangle.v0, o.triangle.v1, o.triangle.v2};
+            for (int ax = 0; ax < 3; ++ax) {
+                const float x0 = v[0].raw[ax], x1 = v[1].raw[ax], x2 = v[2].raw[ax];
+                e[ax] = std::min(x0, std::min(x1, x2));
+                e[ax + 3] = std::max(x0, std::max(x1, x2));
+            }
+            if (!(e[0] <= e[3])) { // NaN vertex: no extent of its own
+                e[0] = 1.0f;
+                e[3] = 0.0f;
+            }
+        }
+        const pt::BvhHost bvh = pt::build_bvh(geom, n_obj, corners.data());
         const size_t node_bytes = bvh.nodes.size() * sizeof(pt::F4);
         const size_t order_bytes = bvh.order.size() * sizeof(uint32_t);
         const size_t unb_bytes = bvh.unbounded.size() * sizeof(uint32_t);

@@ -179,6 +179,52 @@ def test_nan_rays_hit_the_last_sphere_in_every_scan_form(gpu, oracle):
             assert (got[0] == -1).all(), hex(flag)
 
 
+def test_bvh_on_meshes_agrees_with_the_plain_scan_on_hard_rays(gpu):
+    """Triangle boxes in the hierarchy are the vertices' own extent, padded.
+    Rays chosen to stress that: grazing a flat triangulated floor from 1e-3
+    and 1e-5 above it at angles down to 1e-6 rad, aimed at edges and vertices,
+    and rays from 3e4 units away at triangles 0.05 wide."""
+    rng = np.random.default_rng(23)
+    n = 33
+    xs = np.linspace(-8, 8, n); zs = np.linspace(2, 18, n)
+    with gpu.HostScene() as s:
+        s.set_sky(0.5, 0.6, 0.7)
+        mats = [s.add_material(tuple(rng.uniform(0.2, 0.9, 3))) for _ in range(7)]
+        for i in range(n - 1):
+            for k in range(n - 1):
+                a = (xs[i], -1.0, zs[k]); b = (xs[i + 1], -1.0, zs[k])
+                c = (xs[i + 1], -1.0, zs[k + 1]); e = (xs[i], -1.0, zs[k + 1])
+                s.add_triangle(a, b, c, mats[(i + k) % 7])
+                s.add_triangle(a, e, c, mats[(i * k) % 7])
+        for i in range(40):                                  # a cloud of tiny triangles
+            c = np.array([rng.uniform(-1, 1), rng.uniform(0, 2), rng.uniform(8, 10)])
+            s.add_triangle(tuple(c), tuple(c + rng.uniform(-0.05, 0.05, 3)),
+                           tuple(c + rng.uniform(-0.05, 0.05, 3)), mats[i % 7])
+        s.add_sphere((0, 0.5, 9), 0.4, mats[0])
+        m = 200000
+        # targets on the floor: grid vertices, edge midpoints, random points
+        gi = rng.integers(0, n, m); gk = rng.integers(0, n, m)
+        tx = xs[gi] + np.where(rng.integers(0, 3, m) == 0, 0.0, rng.uniform(-0.5, 0.5, m)) * (rng.integers(0, 2, m))
+        tz = zs[gk] + rng.choice([0.0, 0.25, 1e-4], m) * rng.uniform(-1, 1, m)
+        theta = 10.0 ** rng.uniform(-6, -1, m)
+        phi = rng.uniform(0, 2 * np.pi, m)
+        height = rng.choice([1e-3, 1e-5, 0.3], m)
+        d = np.stack([np.cos(phi) * np.cos(theta), -np.sin(theta), np.sin(phi) * np.cos(theta)], 1)
+        o = np.stack([tx, np.full(m, -1.0), tz], 1) - d * (height / np.sin(theta))[:, None]
+        far = rng.normal(size=(20000, 3)); far /= np.linalg.norm(far, axis=1, keepdims=True)
+        o_far = np.array([0, 1, 9]) + far * 3e4 + rng.uniform(-1, 1, (20000, 3))
+        d_far = -far
+        o = np.concatenate([o, o_far]).astype(f32); d = np.concatenate([d, d_far])
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(f32)
+        plain = gpu.trace_rays(s, o, d)
+        assert (plain[0] > 0).sum() > 50000
+        for flag in (gpu._abi.FLAG_SCAN_SCREENED, gpu._abi.FLAG_SCAN_BVH):
+            other = gpu.trace_rays(s, o, d, flag)
+            assert np.array_equal(bits(plain[0]), bits(other[0])), hex(flag)
+            hit = plain[0] >= 0
+            assert np.array_equal(plain[3][hit], other[3][hit]), hex(flag)
+
+
 def test_legacy_trace_ray_single_query(gpu, oracle):
     V = gpu._abi.Vec3
     with gpu.HostScene(0) as s:
