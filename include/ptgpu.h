@@ -155,6 +155,13 @@ typedef struct ptgpu_stats {
     uint64_t scans;       /* closest-hit scans of the scene actually executed.
                              Equals `rays` unless the primary segment's scan
                              was shared between the samples of a pixel */
+    double kernel_ms;     /* device time of the render / accumulate calls
+                             (first to last kernel of each call, HIP events
+                             on the call's stream), summed over calls */
+    uint64_t hbm_bytes;   /* algorithmic HBM bytes those calls moved: 3 per
+                             pixel of a fused render, 32 per pixel of an
+                             accumulate pass, 32 per sample of a sample-queue
+                             pass (+ its accumulator traffic) */
 } ptgpu_stats;
 
 /* Opaque device-resident scene (geometry + materials in HBM, laid out for the

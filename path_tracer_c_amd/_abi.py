@@ -154,7 +154,8 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64),
                 ("wave_iters", C.c_uint64), ("launches", C.c_uint64),
-                ("scans", C.c_uint64)]
+                ("scans", C.c_uint64), ("kernel_ms", C.c_double),
+                ("hbm_bytes", C.c_uint64)]
 
 
 assert C.sizeof(Vec3) == 12 and C.sizeof(Sphere) == 16

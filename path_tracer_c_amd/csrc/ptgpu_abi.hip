@@ -733,6 +733,82 @@ int scratch_for_current_device(DeviceScratch **out) {
     return PTGPU_OK;
 }
 
+// Device time and algorithmic bytes of the render calls, for ptgpu_stats.  A
+// call brackets its kernels with two events on its stream; pairs are turned
+// into milliseconds once they have completed (never waited for).
+struct DeviceTiming {
+    std::mutex lock;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<hipEvent_t> spare;
+    double ms = 0.0;
+    unsigned long long bytes = 0;
+
+    hipEvent_t take() { // lock held
+        if (!spare.empty()) {
+            hipEvent_t e = spare.back();
+            spare.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+    }
+    void harvest() {
+        std::lock_guard<std::mutex> guard(lock);
+        size_t kept = 0;
+        for (auto &pr : pending) {
+            float t = 0.0f;
+            if (hipEventQuery(pr.second) == hipSuccess &&
+                hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) {
+                ms += t;
+                spare.push_back(pr.first);
+                spare.push_back(pr.second);
+            } else {
+                pending[kept++] = pr;
+            }
+        }
+        pending.resize(kept);
+        (void)hipGetLastError(); // hipEventQuery reports "not ready" as an error
+    }
+};
+DeviceTiming g_timing[kMaxDevices];
+
+// Brackets one call's work on `stream`.
+struct TimedCall {
+    DeviceTiming *t = nullptr;
+    hipStream_t stream;
+    hipEvent_t begin = nullptr, end = nullptr;
+    TimedCall(bool enabled, hipStream_t st) : stream(st) {
+        int dev = 0;
+        if (!enabled || current_device(&dev) != PTGPU_OK)
+            return;
+        t = &g_timing[dev];
+        std::lock_guard<std::mutex> guard(t->lock);
+        begin = t->take();
+        end = t->take();
+        if (begin == nullptr || end == nullptr || hipEventRecord(begin, stream) != hipSuccess)
+            t = nullptr;
+    }
+    void add_bytes(unsigned long long n) {
+        if (t != nullptr) {
+            std::lock_guard<std::mutex> guard(t->lock);
+            t->bytes += n;
+        }
+    }
+    ~TimedCall() {
+        if (t == nullptr)
+            return;
+        bool many = false;
+        {
+            std::lock_guard<std::mutex> guard(t->lock);
+            if (hipEventRecord(end, stream) == hipSuccess)
+                t->pending.emplace_back(begin, end);
+            many = t->pending.size() > 64;
+        }
+        if (many)
+            t->harvest();
+    }
+};
+
 enum Mode { kPixelOwner = 0, kSampleQueue = 1 };
 
 // One frame's worth of work for both public entry points.  Exactly one of
@@ -750,6 +826,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         return rc;
     const uint64_t npix = (uint64_t)a.num_rows * a.framew;
     const uint32_t total_spp = a.spp;
+    TimedCall timed(a.counters != nullptr, stream); // part of the statistics
 
     // ---- which schedule ------------------------------------------------------
     int mode = s->queue_mode.load();
@@ -831,6 +908,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         if (e != hipSuccess)
             return fail_hip(e, "megakernel launch");
         count_launch();
+        timed.add_bytes((d_frame != nullptr ? 3ull : 32ull) * npix);
         return PTGPU_OK;
     }
 
@@ -901,6 +979,9 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         if (e != hipSuccess)
             return fail_hip(e, "sample kernel launch");
         count_launch();
+        // samples stored and read back in order; accumulator read (unless this
+        // is its first pass) and written, or the frame written
+        timed.add_bytes(32ull * npix * k + (accum_is_zero ? 0ull : 16ull * npix) + 16ull * npix);
         done_spp += k;
         q.first_pass = accum_is_zero ? 1u : 0u;
         accum_is_zero = false;
@@ -987,6 +1068,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
                 if (e != hipSuccess)
                     return fail_hip(e, "megakernel launch (pilot)");
                 count_launch();
+                timed.add_bytes(32ull * npix);
                 done_spp += count;
             }
             PT_TRY_HIP(hipEventRecord(ev[1], stream));
@@ -1054,6 +1136,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
             if (e != hipSuccess)
                 return fail_hip(e, "megakernel launch (accumulate)");
             count_launch();
+            timed.add_bytes(32ull * npix);
         }
         if (d_frame != nullptr) { // resolve the scratch accumulator
             pt::LaunchArgs q = a;
@@ -1063,6 +1146,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
             hipError_t e = pt::launch_sum(q, stream);
             if (e != hipSuccess)
                 return fail_hip(e, "resolve launch");
+            timed.add_bytes(19ull * npix);
         }
         return PTGPU_OK;
     }
@@ -1367,6 +1451,16 @@ int ptgpu_trace_rays_scan(const scene *host_scene, const float *origins,
 // bookkeeping
 // ---------------------------------------------------------------------------
 int ptgpu_stats_reset(void) {
+    {
+        int d = 0;
+        if (current_device(&d) == PTGPU_OK) {
+            (void)hipDeviceSynchronize();
+            g_timing[d].harvest();
+            std::lock_guard<std::mutex> guard(g_timing[d].lock);
+            g_timing[d].ms = 0.0;
+            g_timing[d].bytes = 0;
+        }
+    }
     pt::Counters *c = nullptr;
     int rc = counters_for_current_device(&c);
     if (rc != PTGPU_OK)
@@ -1397,6 +1491,14 @@ int ptgpu_stats_read(ptgpu_stats *out) {
     out->scans = host.scans;
     int dev = 0;
     out->launches = (current_device(&dev) == PTGPU_OK) ? g_launches[dev].load() : 0;
+    out->kernel_ms = 0.0;
+    out->hbm_bytes = 0;
+    if (current_device(&dev) == PTGPU_OK) {
+        g_timing[dev].harvest(); // the device is idle: every pair has completed
+        std::lock_guard<std::mutex> guard(g_timing[dev].lock);
+        out->kernel_ms = g_timing[dev].ms;
+        out->hbm_bytes = g_timing[dev].bytes;
+    }
     return PTGPU_OK;
 }
 

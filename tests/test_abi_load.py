@@ -53,7 +53,7 @@ def test_layouts_match_the_reference_headers(pt):
     assert C.sizeof(a.RayHit) == 40 and a.RayHit.material.offset == 32
     assert C.sizeof(a.RenderArgs) == 40 and a.RenderArgs.frame.offset == 24
     assert C.sizeof(a.ThreadPool) == 192
-    assert C.sizeof(a.Params) == 52 and C.sizeof(a.Stats) == 40
+    assert C.sizeof(a.Params) == 52 and C.sizeof(a.Stats) == 56
 
 
 def test_default_params_are_the_reference_macros(pt):

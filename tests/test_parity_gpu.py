@@ -398,6 +398,32 @@ def test_lanes_per_pixel_progressive_and_stats(gpu):
         assert accs[0][1] == accs[1][1]
 
 
+def test_stats_report_device_time_and_algorithmic_bytes(gpu, torch_cuda):
+    torch = torch_cuda
+    w, h = 96, 50
+    with gpu.HostScene(2) as s, gpu.DeviceScene(s) as d:
+        st = torch.cuda.current_stream().cuda_stream
+        out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+        acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        gpu.host.reset_stats()
+        zero = gpu.host.read_stats()
+        assert zero.kernel_ms == 0.0 and zero.hbm_bytes == 0 and zero.rays == 0
+        d.render(out.data_ptr(), w, h, gpu.make_params(spp=4, flags=0x80), st)
+        one = gpu.host.read_stats()
+        assert one.hbm_bytes == 3 * w * h and 0.0 < one.kernel_ms < 1000.0
+        for i in range(3):
+            d.accumulate(acc.data_ptr(), w, h, gpu.make_params(spp=2, sample_offset=2 * i, flags=0x80), st)
+        two = gpu.host.read_stats()
+        assert two.hbm_bytes == 3 * w * h + 3 * 32 * w * h and two.kernel_ms > one.kernel_ms
+        d.render(out.data_ptr(), w, h, gpu.make_params(spp=4, flags=0x100), st)      # one queue pass
+        three = gpu.host.read_stats()
+        assert three.hbm_bytes - two.hbm_bytes == (32 * 4 + 16) * w * h
+        d.render(out.data_ptr(), w, h, gpu.make_params(spp=4, flags=0x88), st)       # not counted
+        assert gpu.host.read_stats().hbm_bytes == three.hbm_bytes
+        gpu.host.reset_stats()
+        assert gpu.host.read_stats().kernel_ms == 0.0
+
+
 def test_bad_lanes_per_pixel_is_refused(gpu):
     with gpu.HostScene(0) as s:
         for k in (3, 65, 128):
