@@ -801,6 +801,70 @@ __global__ void __launch_bounds__(1024) pt_megakernel(const LaunchArgs a) {
     count_block(a.counters, w.tally, rays, scans, samples_done, iters, tid, nthreads);
 }
 
+// ---- task hand-out shared by the two sample-queue kernels ---------------------
+// Wave-uniform cursor over the chunks (64 tasks each) this wave has reserved.
+struct ChunkCursor {
+    uint32_t pos = 64u;    // tasks of the current chunk already handed out
+    uint32_t sample = 0u;  // the current chunk's sample index ...
+    uint32_t j0 = 0u;      // ... and first local pixel
+    uint32_t next = 0u, limit = 0u; // reserved chunks not yet started
+    bool dry = false;      // the global pool has no chunk left
+};
+
+// One round of hand-out: the lanes of `free_mask` (this lane: `is_free`) get
+// the next tasks of the wave's current chunk in lane order -- a lane's place
+// among the free lanes is the popcount of the mask below it.  Returns true if
+// this lane got a task: sample index and local pixel j (j >= npix is a padding
+// slot of the last chunk of a sample: the lane stays free).  A wave reserves
+// a.chunk_batch chunks with one atomic on the global counter.  Callers loop
+// while free lanes remain and !dry.
+__device__ __forceinline__ bool take_task(ChunkCursor &c, const LaunchArgs &a,
+                                          uint32_t *chunk_counter,
+                                          unsigned long long free_mask, bool is_free,
+                                          uint32_t lane, uint32_t &sample, uint32_t &j) {
+    if (c.pos >= 64u) {
+        if (c.next >= c.limit) {
+            const int leader = __ffsll((long long)free_mask) - 1;
+            uint32_t first = 0;
+            if ((int)lane == leader)
+                first = atomicAdd(chunk_counter, a.chunk_batch);
+            first = __shfl(first, leader, 64);
+            if (first >= a.num_chunks) {
+                c.dry = true;
+                return false;
+            }
+            c.next = first;
+            c.limit = first + a.chunk_batch < a.num_chunks ? first + a.chunk_batch : a.num_chunks;
+        }
+        const uint32_t chunk = c.next++;
+        c.sample = chunk / a.chunks_per_sample;
+        c.j0 = (chunk - c.sample * a.chunks_per_sample) * 64u;
+        c.pos = 0u;
+    }
+    const uint32_t avail = 64u - c.pos;
+    const uint32_t rank = (uint32_t)__popcll(free_mask & ((1ull << lane) - 1ull));
+    const bool got = is_free && rank < avail;
+    sample = c.sample;
+    j = c.j0 + c.pos + rank;
+    const uint32_t wanted = (uint32_t)__popcll(free_mask);
+    c.pos += wanted < avail ? wanted : avail;
+    return got;
+}
+
+// A fresh path for local pixel j, sample `sample` (src/renderer.c:76-87).
+__device__ __forceinline__ void start_path(const LaunchArgs &a, uint32_t j, uint32_t sample,
+                                           PathState &p, uint32_t &out_index) {
+    const PixelSite ps = pixel_site(a, j);
+    out_index = sample * a.npix_pad + j;
+    p.o = splat(0.0f);
+    p.d = ps.d0;
+    p.r = splat(0.0f);
+    p.depth = 0;
+    p.rng = ptgpu_rng_seed(a.seed, ps.pixel, a.sample_offset + sample);
+    p.live = true;
+    p.parked = false;
+}
+
 // ---------------------------------------------------------------------------
 // Kernel 2: sample-queue mode.  The unit of work is one (pixel, sample) path.
 //
@@ -847,13 +911,10 @@ __global__ void __launch_bounds__(1024)
     const V3 sky = V3{a.scene.sky[0], a.scene.sky[1], a.scene.sky[2]};
     const uint32_t npix = a.num_rows * a.framew;
 
-    // wave-uniform cursor: a wave reserves a.chunk_batch chunks with one atomic
     // (one global counter sustains only ~90 atomics per microsecond chip-wide;
-    // per-chunk atomics made the counter, not the ALUs, the bottleneck) and
-    // walks them one after the other
-    uint32_t chunk_pos = 64u, chunk_sample = 0u, chunk_j0 = 0u;
-    uint32_t next_chunk = 0u, chunk_limit = 0u;
-    bool pool_dry = false;
+    // per-chunk atomics made the counter, not the ALUs, the bottleneck: hence
+    // several chunks per reservation)
+    ChunkCursor cursor;
 
     bool have = false; // this lane owns a task
     uint32_t out_index = 0;
@@ -867,48 +928,12 @@ __global__ void __launch_bounds__(1024)
     for (;;) {
         // ---- refill free lanes from the wave's chunk (ballot + prefix sum) ----
         unsigned long long free_mask = __ballot(!have);
-        while (free_mask != 0ull && !pool_dry) {
-            if (chunk_pos >= 64u) {
-                if (next_chunk >= chunk_limit) {
-                    const int leader = __ffsll((long long)free_mask) - 1;
-                    uint32_t c = 0;
-                    if ((int)lane == leader)
-                        c = atomicAdd(chunk_counter, a.chunk_batch);
-                    c = __shfl(c, leader, 64);
-                    if (c >= a.num_chunks) {
-                        pool_dry = true;
-                        break;
-                    }
-                    next_chunk = c;
-                    chunk_limit = c + a.chunk_batch < a.num_chunks ? c + a.chunk_batch
-                                                                 : a.num_chunks;
-                }
-                const uint32_t c = next_chunk++;
-                chunk_sample = c / a.chunks_per_sample;
-                chunk_j0 = (c - chunk_sample * a.chunks_per_sample) * 64u;
-                chunk_pos = 0u;
+        while (free_mask != 0ull && !cursor.dry) {
+            uint32_t sample, j;
+            if (take_task(cursor, a, chunk_counter, free_mask, !have, lane, sample, j) && j < npix) {
+                have = true;
+                start_path(a, j, sample, p, out_index);
             }
-            const uint32_t avail = 64u - chunk_pos;
-            const uint32_t rank =
-                (uint32_t)__popcll(free_mask & ((1ull << lane) - 1ull));
-            if (!have && rank < avail) {
-                const uint32_t j = chunk_j0 + chunk_pos + rank;
-                if (j < npix) { // else: padding slot of the last chunk of a sample
-                    const PixelSite ps = pixel_site(a, j);
-                    have = true;
-                    out_index = chunk_sample * a.npix_pad + j;
-                    p.o = splat(0.0f);
-                    p.d = ps.d0;
-                    p.r = splat(0.0f);
-                    p.depth = 0;
-                    p.rng = ptgpu_rng_seed(a.seed, ps.pixel,
-                                           a.sample_offset + chunk_sample);
-                    p.live = true;
-                    p.parked = false;
-                }
-            }
-            const uint32_t wanted = (uint32_t)__popcll(free_mask);
-            chunk_pos += wanted < avail ? wanted : avail;
             free_mask = __ballot(!have);
         }
         if (__ballot(have) == 0ull)
@@ -977,9 +1002,7 @@ __global__ void __launch_bounds__(1024)
     const V3 sky = V3{a.scene.sky[0], a.scene.sky[1], a.scene.sky[2]};
     const uint32_t npix = a.num_rows * a.framew;
 
-    uint32_t chunk_pos = 64u, chunk_sample = 0u, chunk_j0 = 0u;
-    uint32_t next_chunk = 0u, chunk_limit = 0u;
-    bool pool_dry = false;
+    ChunkCursor cursor;
 
     enum : uint32_t { kFree = 0, kFresh = 1, kWalk = 2, kHit = 3, kParked = 4 };
     uint32_t st = kFree;
@@ -1015,7 +1038,7 @@ __global__ void __launch_bounds__(1024)
         }
         const unsigned long long walking = __ballot(st == kWalk);
         const unsigned long long waiting =
-            __ballot(st == kHit || st == kParked || (st == kFree && !pool_dry));
+            __ballot(st == kHit || st == kParked || (st == kFree && !cursor.dry));
         if (walking == 0ull || (uint32_t)__popcll(waiting) >= a.settle_lanes) {
             // ---- service -----------------------------------------------------------
             PT_BVH_COUNT(6, st == kHit);
@@ -1032,48 +1055,13 @@ __global__ void __launch_bounds__(1024)
             }
             // refill free lanes from the wave's chunk (as pt_samplekernel does)
             unsigned long long free_mask = __ballot(st == kFree);
-            while (free_mask != 0ull && !pool_dry) {
-                if (chunk_pos >= 64u) {
-                    if (next_chunk >= chunk_limit) {
-                        const int leader = __ffsll((long long)free_mask) - 1;
-                        uint32_t c = 0;
-                        if ((int)lane == leader)
-                            c = atomicAdd(chunk_counter, a.chunk_batch);
-                        c = __shfl(c, leader, 64);
-                        if (c >= a.num_chunks) {
-                            pool_dry = true;
-                            break;
-                        }
-                        next_chunk = c;
-                        chunk_limit = c + a.chunk_batch < a.num_chunks ? c + a.chunk_batch
-                                                                     : a.num_chunks;
-                    }
-                    const uint32_t c = next_chunk++;
-                    chunk_sample = c / a.chunks_per_sample;
-                    chunk_j0 = (c - chunk_sample * a.chunks_per_sample) * 64u;
-                    chunk_pos = 0u;
+            while (free_mask != 0ull && !cursor.dry) {
+                uint32_t sample, j;
+                if (take_task(cursor, a, chunk_counter, free_mask, st == kFree, lane, sample, j) &&
+                    j < npix) {
+                    st = kFresh;
+                    start_path(a, j, sample, p, out_index);
                 }
-                const uint32_t avail = 64u - chunk_pos;
-                const uint32_t rank =
-                    (uint32_t)__popcll(free_mask & ((1ull << lane) - 1ull));
-                if (st == kFree && rank < avail) {
-                    const uint32_t j = chunk_j0 + chunk_pos + rank;
-                    if (j < npix) { // else: padding slot of the last chunk of a sample
-                        const PixelSite ps = pixel_site(a, j);
-                        st = kFresh;
-                        out_index = chunk_sample * a.npix_pad + j;
-                        p.o = splat(0.0f);
-                        p.d = ps.d0;
-                        p.r = splat(0.0f);
-                        p.depth = 0;
-                        p.rng = ptgpu_rng_seed(a.seed, ps.pixel,
-                                               a.sample_offset + chunk_sample);
-                        p.live = true;
-                        p.parked = false;
-                    }
-                }
-                const uint32_t wanted = (uint32_t)__popcll(free_mask);
-                chunk_pos += wanted < avail ? wanted : avail;
                 free_mask = __ballot(st == kFree);
             }
             // every new ray starts its walk (a poisoned one gets the

@@ -853,27 +853,9 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
     // wave slots that would stay empty.
     uint32_t owner_block = block; // workgroup size of pixel-owner launches
     auto choose_lanes = [&](bool may_fall_back_to_queue) {
+        owner_block = block;
         if (mode != kPixelOwner || tree)
             return;
-        // On leaving: with k lanes per pixel, workgroups of up to 256
-        // work-items, so that a workgroup's pixels leave as one run of whole
-        // dwords (store_rgb8_block; 192 bytes for k <= 4) and its statistics as
-        // one atomic.  Larger workgroups cost time (C2, k = 8: 62.1 ms at
-        // 64..256, 66.4 at 512).
-        struct FitBlock {
-            pt::LaunchArgs &a;
-            const ptgpu_params *p;
-            uint32_t block, &owner_block;
-            ~FitBlock() {
-                owner_block = block;
-                uint32_t want = 64u * a.lanes_per_pixel;
-                if (want > 256u)
-                    want = 256u;
-                if (a.lanes_per_pixel > 1u && p->block_threads == 0u && want > block &&
-                    pt::megakernel_lds_bytes(a, want, false) <= 64u * 1024u)
-                    owner_block = want;
-            }
-        } fit_block{a, p, block, owner_block};
         DeviceScratch *probe = nullptr;
         if (p->lanes_per_pixel != 0u) {
             a.lanes_per_pixel = p->lanes_per_pixel;
@@ -892,9 +874,20 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
             const double owner_efficiency = fill / std::ceil(fill);
             if (may_fall_back_to_queue && k == 1u && a.counters != nullptr && total_spp >= 16 &&
                 !(p->flags & PTGPU_FLAG_PIXEL_OWNER) &&
-                (fill < 1.5 || (fill < 4.0 && owner_efficiency < 0.85)))
+                (fill < 1.5 || (fill < 4.0 && owner_efficiency < 0.85))) {
                 mode = kSampleQueue;
+                return;
+            }
         }
+        // With k lanes per pixel: workgroups of up to 256 work-items, so that a
+        // workgroup's pixels leave as one run of whole dwords
+        // (store_rgb8_block; 192 bytes for k <= 4) and its statistics as one
+        // atomic.  Larger workgroups cost time (C2, k = 8: 62.1 ms at 64..256
+        // work-items, 66.4 at 512).
+        const uint32_t wanted_block = std::min(256u, 64u * a.lanes_per_pixel);
+        if (a.lanes_per_pixel > 1u && p->block_threads == 0u && wanted_block > block &&
+            pt::megakernel_lds_bytes(a, wanted_block, false) <= 64u * 1024u)
+            owner_block = wanted_block;
     };
     choose_lanes(true);
 
