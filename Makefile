@@ -52,4 +52,23 @@ clean:
 	rm -rf $(BUILD) $(LIBDIR) bin
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean asan-driver
+
+# Host-side AddressSanitizer + UBSan build of the C driver with the library
+# linked in statically: the C-ABI translation unit (all host logic: upload, BVH
+# build, schedule choice, scratch, statistics, legacy shims) and the host C are
+# instrumented; the kernels' translation unit is built plainly (with
+# -Xarch_host -fsanitize on that one the kernels come out as no-ops).  Device
+# code is never instrumented (-Xarch_host / -fno-gpu-sanitize).
+# Run on a GPU box: tools/asan_driver.sh
+ASAN_HOST := -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -fno-omit-frame-pointer
+CLANG     := /opt/rocm/lib/llvm/bin/clang
+asan-driver: | $(BUILD) bin
+	$(HIPCC) $(filter-out -O3,$(HIPFLAGS)) -O1 -g $(ASAN_HOST) -c $(CSRC)/ptgpu_abi.hip -o $(BUILD)/asan_abi.o
+	$(HIPCC) $(filter-out -O3,$(HIPFLAGS)) -O1 -g -c $(CSRC)/device/pt_kernels.hip -o $(BUILD)/asan_kernels.o
+	for f in scene vector bitmap scenes main; do \
+	  $(CLANG) -std=gnu2x -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -ffp-contract=off -Iinclude \
+	    -c $(CSRC)/host/$$f.c -o $(BUILD)/asan_$$f.o || exit 1; done
+	$(HIPCC) --offload-arch=$(ARCH) -fno-gpu-sanitize -fsanitize=address,undefined -o bin/ptrender_asan \
+	  $(BUILD)/asan_main.o $(BUILD)/asan_scene.o $(BUILD)/asan_vector.o $(BUILD)/asan_bitmap.o $(BUILD)/asan_scenes.o \
+	  $(BUILD)/asan_abi.o $(BUILD)/asan_kernels.o -lpthread -lm

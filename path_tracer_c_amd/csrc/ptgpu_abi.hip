@@ -432,9 +432,12 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
         const size_t unb_bytes = bvh.unbounded.size() * sizeof(uint32_t);
         const size_t total = node_bytes + order_bytes + unb_bytes + 16;
         std::vector<unsigned char> packed(total, 0);
-        std::memcpy(packed.data(), bvh.nodes.data(), node_bytes);
-        std::memcpy(packed.data() + node_bytes, bvh.order.data(), order_bytes);
-        std::memcpy(packed.data() + node_bytes + order_bytes, bvh.unbounded.data(), unb_bytes);
+        if (node_bytes) // (memcpy's arguments may not be null, even for 0 bytes)
+            std::memcpy(packed.data(), bvh.nodes.data(), node_bytes);
+        if (order_bytes)
+            std::memcpy(packed.data() + node_bytes, bvh.order.data(), order_bytes);
+        if (unb_bytes)
+            std::memcpy(packed.data() + node_bytes + order_bytes, bvh.unbounded.data(), unb_bytes);
         hipError_t be = hipMalloc(&h->bvh_blob, total);
         if (be == hipSuccess)
             be = hipMemcpy(h->bvh_blob, packed.data(), total, hipMemcpyHostToDevice);

@@ -9,6 +9,7 @@ stream vs the reference's glibc random() stream) states its tolerance inline.
 """
 import ctypes as C
 import os
+import subprocess
 from pathlib import Path
 
 import numpy as np
@@ -713,6 +714,24 @@ def test_primary_scan_sharing_is_invisible_and_accounted(gpu, oracle):
     assert 0 < rays - st_split.scans <= w * h * (spp - 4)
     assert st_plain.scans == rays
     assert w * h <= rays - st_shared.scans <= w * h * (spp - 1)   # at most one scan saved per sample
+
+
+def test_host_code_under_sanitizers_with_real_kernels(gpu, tmp_path):
+    """bin/ptrender_asan (make asan-driver, built by __graft_entry__.build()):
+    the C driver with the C-ABI translation unit and the host C under ASan +
+    UBSan, device code plain.  Legacy path, the pilots and BVH passes of
+    configuration 5, a forced queue, a two-way device split, progressive
+    passes with a resume -- no sanitizer report, and real frames."""
+    root = Path(__file__).resolve().parent.parent
+    exe = root / "bin" / "ptrender_asan"
+    assert exe.exists(), "bin/ptrender_asan missing: run `make asan-driver` (build() does)"
+    run = subprocess.run(["bash", str(root / "tools" / "asan_driver.sh"), str(tmp_path)],
+                         cwd=root, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    assert "asan_driver: ok" in run.stdout
+    assert "runtime error" not in run.stderr and "Sanitizer" not in run.stderr, run.stderr[-4000:]
+    pixels = _bmp_pixels(tmp_path / "c5.bmp", 1920, 1080)
+    assert pixels.mean() > 10                      # a real frame, not a black one
 
 
 def _random_scene(gpu, rng, branching):
