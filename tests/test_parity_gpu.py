@@ -748,7 +748,7 @@ def _random_scene(gpu, rng, branching):
                        emission_color=tuple(rng.uniform(0, 1, 3)),
                        emission_strength=float(rng.choice([0.0, 0.0, 1.0, 10.0])),
                        transparency=float(rng.choice(t_choices)), refractive_index=1.5)
-    n_obj = int(rng.choice([1, 2, 5, 9, 31, 32, 33, 70]))
+    n_obj = int(rng.choice([1, 2, 5, 9, 31, 32, 33, 70, 70, 150, 400]))   # hierarchy from 64 up
     for _ in range(n_obj):
         c = rng.normal(0, 3, 3) * scale + np.array([0, 0, 4 * scale])
         m = int(rng.integers(n_mat))
