@@ -255,6 +255,14 @@ int ptgpu_trace_rays_scan(const scene *host_scene, const float *origins,
                           const float *directions, size_t n, ray_hit *hits,
                           uint32_t scan_flags);
 
+/* The same for rays that already live in HBM: asynchronous on `hip_stream`;
+ * d_origins / d_directions: n x 3 floats, d_hits: n ray_hit records (40 bytes
+ * each), all device pointers.  64 bytes of HBM traffic per ray: with a small
+ * scene this kernel is bound by HBM, not by the ALUs. */
+int ptgpu_trace_rays_device(const ptgpu_scene *s, const float *d_origins,
+                            const float *d_directions, size_t n, ray_hit *d_hits,
+                            uint32_t scan_flags, void *hip_stream);
+
 /* -- bookkeeping ------------------------------------------------------------ */
 int ptgpu_stats_reset(void);
 int ptgpu_stats_read(ptgpu_stats *out); /* synchronises the device */

@@ -222,6 +222,8 @@ SIGNATURES = {
                                    C.c_size_t, C.c_void_p]),
     "ptgpu_trace_rays_scan": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_void_p,
                                         C.c_size_t, C.c_void_p, C.c_uint32]),
+    "ptgpu_trace_rays_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                          C.c_void_p, C.c_uint32, C.c_void_p]),
     "ptgpu_stats_reset": (C.c_int, []),
     "ptgpu_stats_read": (C.c_int, [C.POINTER(Stats)]),
     "ptgpu_last_error": (C.c_char_p, []),

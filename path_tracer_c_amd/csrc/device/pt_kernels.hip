@@ -1198,9 +1198,48 @@ __global__ void __launch_bounds__(256)
     queue.slot = reinterpret_cast<uint32_t *>(lds_dyn) + threadIdx.x;
     queue.stride = blockDim.x;
     queue.stack = queue.slot + kScreenQueue * blockDim.x;
-    const V3 o = V3{origins[3 * at], origins[3 * at + 1], origins[3 * at + 2]};
-    const V3 d = V3{directions[3 * at], directions[3 * at + 1],
-                    directions[3 * at + 2]};
+    // Rays in and hits out are arrays of 12- and 40-byte records.  A wave's 64
+    // of them are 768 / 2560 contiguous bytes: moved as whole 16-byte words
+    // (48 / 160 of them per wave) and re-dealt to the lanes through LDS,
+    // because with a small scene this kernel is bound by HBM (64 bytes per
+    // ray), and 4-byte accesses with a 12- or 40-byte stride waste it.
+    // `staged` (wave-uniform): the wave is full and the arrays are 16-byte
+    // aligned; otherwise every lane moves its own record word by word.
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave_first = i - lane;
+    const bool staged = wave_first + 64u <= n &&
+                        ((reinterpret_cast<uintptr_t>(origins) | reinterpret_cast<uintptr_t>(directions) |
+                          reinterpret_cast<uintptr_t>(hits)) & 15u) == 0u;
+    // Staging area, 640 words per wave.  Plain scan: a contiguous run.
+    // Screened / BVH scan: the wave's share of the candidate queues and
+    // stacks (idle before and after the scan) -- word j sits in row j / 64 of
+    // the block-wide rows, at the wave's 64 columns -- so that staging costs
+    // those kernels no LDS of its own (10 KB more per workgroup cost the BVH
+    // form 15 %).
+    uint32_t *const lds_words = reinterpret_cast<uint32_t *>(lds_dyn);
+    const uint32_t wave_column = threadIdx.x & ~63u;
+    auto stage_word = [&](uint32_t j) -> uint32_t * {
+        if (kScan == 0)
+            return lds_words + 10u * wave_column + j;
+        return lds_words + (j >> 6) * blockDim.x + wave_column + (j & 63u);
+    };
+    V3 o, d;
+    if (staged) {
+        const uint4 *src_o = reinterpret_cast<const uint4 *>(origins + 3u * wave_first);
+        const uint4 *src_d = reinterpret_cast<const uint4 *>(directions + 3u * wave_first);
+        if (lane < 48u) {
+            *reinterpret_cast<uint4 *>(stage_word(4u * lane)) = src_o[lane];
+            *reinterpret_cast<uint4 *>(stage_word(192u + 4u * lane)) = src_d[lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+        auto word = [&](uint32_t j) { return __builtin_bit_cast(float, *stage_word(j)); };
+        o = V3{word(3u * lane), word(3u * lane + 1u), word(3u * lane + 2u)};
+        d = V3{word(192u + 3u * lane), word(192u + 3u * lane + 1u), word(192u + 3u * lane + 2u)};
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        o = V3{origins[3 * at], origins[3 * at + 1], origins[3 * at + 2]};
+        d = V3{directions[3 * at], directions[3 * at + 1], directions[3 * at + 2]};
+    }
     const Hit h = scan_scene<kScan>(rec, o, d, queue);
     DeviceRayHit out;
     out.distance = h.distance;
@@ -1218,8 +1257,22 @@ __global__ void __launch_bounds__(256)
         out.normal[2] = sf.normal.z;
         out.material = sf.material;
     }
-    if (valid)
+    if (staged) {
+        static_assert(sizeof(DeviceRayHit) == 40, "ray_hit is 10 words");
+        uint32_t words[10];
+        __builtin_memcpy(words, &out, sizeof out);
+#pragma unroll
+        for (uint32_t k = 0; k < 10u; ++k)
+            *stage_word(10u * lane + k) = words[k];
+        __builtin_amdgcn_wave_barrier();
+        uint4 *dst = reinterpret_cast<uint4 *>(hits + wave_first);
+        dst[lane] = *reinterpret_cast<const uint4 *>(stage_word(4u * lane));
+        dst[64u + lane] = *reinterpret_cast<const uint4 *>(stage_word(256u + 4u * lane));
+        if (lane < 32u)
+            dst[128u + lane] = *reinterpret_cast<const uint4 *>(stage_word(512u + 4u * lane));
+    } else if (valid) {
         hits[i] = out;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1398,7 +1451,10 @@ hipError_t launch_trace(const SceneDesc &scene, const float *origins,
     if (n == 0)
         return hipSuccess;
     const uint32_t grid = (uint32_t)((n + 255u) / 256u);
-    const size_t lds = (size_t)4 * 256u * (kScreenQueue + scene.bvh_depth + 2u);
+    // rows of 256 words: candidate queues + traversal stacks (screened / BVH
+    // scan), doubling as the waves' staging areas (10 rows)
+    const uint32_t rows = scan == 0 ? 10u : kScreenQueue + scene.bvh_depth + 2u;
+    const size_t lds = (size_t)4 * 256u * rows;
     if (scan == 2)
         hipLaunchKernelGGL(pt_trace_kernel<2>, dim3(grid), dim3(256), lds, stream,
                            scene, origins, directions, n, hits);

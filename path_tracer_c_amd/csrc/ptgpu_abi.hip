@@ -1014,10 +1014,10 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         } else if (n_obj < 64u || !has_bvh) {
             cand[n_cand++] = 0u;
             cand[n_cand++] = 1u;
-        } else if (n_obj < 4096u) {
+        } else if (n_obj < 512u) {
             cand[n_cand++] = 1u;
             cand[n_cand++] = 2u;
-        } else {
+        } else { // (tools/bvh_scaling.py: 1.3x at 250 objects, 2.8x at 1000)
             cand[n_cand++] = 2u;
         }
         // 1 + 2 * 3 samples per candidate: 14 in all at most; can_measure
@@ -1440,6 +1440,33 @@ int ptgpu_trace_rays_scan(const scene *host_scene, const float *origins,
     ptgpu_scene_free(s);
     if (e != hipSuccess)
         return fail_hip(e, "trace_rays");
+    return PTGPU_OK;
+}
+
+int ptgpu_trace_rays_device(const ptgpu_scene *s, const float *d_origins,
+                            const float *d_directions, size_t n, ray_hit *d_hits,
+                            uint32_t scan_flags, void *hip_stream) {
+    if (s == nullptr)
+        return fail(PTGPU_ERR_INVALID, "scene is NULL");
+    if (n == 0)
+        return PTGPU_OK;
+    if (d_origins == nullptr || d_directions == nullptr || d_hits == nullptr)
+        return fail(PTGPU_ERR_INVALID, "NULL ray buffer");
+    if (n > 0xFFFFFFFFull * 256ull)
+        return fail(PTGPU_ERR_LIMIT, "too many rays for one call");
+    int scan = 0;
+    if (scan_flags & PTGPU_FLAG_SCAN_SCREENED)
+        scan = 1;
+    if (scan_flags & PTGPU_FLAG_SCAN_BVH) {
+        if (s->desc.bvh_nodes == nullptr)
+            return fail(PTGPU_ERR_INVALID, "scene has no hierarchy (fewer than 64 objects)");
+        scan = 2;
+    }
+    hipError_t e = pt::launch_trace(s->desc, d_origins, d_directions, n,
+                                    reinterpret_cast<pt::DeviceRayHit *>(d_hits), scan,
+                                    (hipStream_t)hip_stream);
+    if (e != hipSuccess)
+        return fail_hip(e, "trace_rays_device");
     return PTGPU_OK;
 }
 

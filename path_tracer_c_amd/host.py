@@ -198,6 +198,15 @@ class DeviceScene:
         check(lib().ptgpu_scene_hierarchy(self.handle, C.byref(nodes), C.byref(depth)))
         return nodes.value, depth.value
 
+    def trace(self, d_origins_ptr: int, d_directions_ptr: int, n: int, d_hits_ptr: int,
+              scan_flags: int = 0, stream: int = 0):
+        """ptgpu_trace_rays_device: n x 3 float origins / directions and n
+        40-byte ray_hit records, all in HBM; asynchronous on `stream`."""
+        check(lib().ptgpu_trace_rays_device(self.handle, C.c_void_p(d_origins_ptr),
+                                            C.c_void_p(d_directions_ptr), n,
+                                            C.c_void_p(d_hits_ptr), scan_flags,
+                                            C.c_void_p(stream)))
+
     def render(self, d_frame_ptr: int, width: int, height: int, params: Params,
                stream: int = 0):
         check(lib().ptgpu_render_device(self.handle, C.c_void_p(d_frame_ptr),

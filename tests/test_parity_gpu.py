@@ -226,6 +226,35 @@ def test_bvh_on_meshes_agrees_with_the_plain_scan_on_hard_rays(gpu):
             assert np.array_equal(plain[3][hit], other[3][hit]), hex(flag)
 
 
+@pytest.mark.parametrize("flag", [0, 0x20, 0x400], ids=["plain", "screened", "bvh"])
+def test_device_resident_trace_equals_the_host_buffer_one(gpu, torch_cuda, flag):
+    """ptgpu_trace_rays_device moves a wave's rays and hits as whole 16-byte
+    words through LDS; ragged counts, a tail wave and unaligned arrays take
+    the word-by-word path.  Same hits either way."""
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    n = 64 * 1000 + 37
+    d_np = rng.normal(size=(n, 3)).astype(f32); d_np /= np.linalg.norm(d_np, axis=1, keepdims=True).astype(f32)
+    o_np = (rng.uniform(-1, 1, (n, 3)) * np.array([10, 1, 10]) + np.array([0, 2, 20])).astype(f32)
+    with gpu.HostScene(5) as s, gpu.DeviceScene(s) as dev:
+        ref = gpu.trace_rays(s, o_np, d_np, flag)
+        st = torch.cuda.current_stream().cuda_stream
+        for shift in (0, 1):                                  # 1: arrays start 4 bytes off a 16-byte boundary
+            o = torch.zeros(3 * n + 4, dtype=torch.float32, device="cuda")
+            d = torch.zeros(3 * n + 4, dtype=torch.float32, device="cuda")
+            o[shift:shift + 3 * n] = torch.from_numpy(o_np.reshape(-1)).cuda()
+            d[shift:shift + 3 * n] = torch.from_numpy(d_np.reshape(-1)).cuda()
+            hits = torch.full((10 * n + 4,), -7.0, dtype=torch.float32, device="cuda")
+            dev.trace(o.data_ptr() + 4 * shift, d.data_ptr() + 4 * shift, n,
+                      hits.data_ptr() + 8 * shift, flag, st)   # (ray_hit needs 8-byte alignment)
+            torch.cuda.synchronize()
+            got = gpu.host.hits_to_arrays(hits.cpu().numpy()[2 * shift:2 * shift + 10 * n].tobytes(), n)
+            for a, b in zip(got, ref):
+                assert np.array_equal(bits(np.asarray(a)) if a.dtype == f32 else a,
+                                      bits(np.asarray(b)) if b.dtype == f32 else b), (hex(flag), shift)
+            assert float(hits[10 * n + 2 * shift:].min()) == -7.0       # nothing written past the end
+
+
 def test_legacy_trace_ray_single_query(gpu, oracle):
     V = gpu._abi.Vec3
     with gpu.HostScene(0) as s:
