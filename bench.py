@@ -369,6 +369,37 @@ def main():
             line["config"]["host_frame_ms"] = (time.perf_counter() - t0) * 1e3
             line["config"]["host_frame_note"] = ("ptgpu_render_frame: scene upload + kernel + "
                                                  f"{3 * w * h / 1e6:.1f} MB download, library defaults")
+        if world == 1 and not progressive:
+            # the batched trace_ray kernel (src/ray.c:4-73 per ray) on rays
+            # resident in HBM: the eye rays of a 4096x4096 image through this
+            # scene.  64 algorithmic bytes per ray (24 in, 40 out): HBM-bound
+            # when the scene is small.  Reported beside the headline.
+            n_rays = 1 << 24
+            ix = torch.arange(n_rays, device="cuda")
+            dx = (ix % 4096).float() / 4096 * 2 - 1
+            dy = -((ix // 4096).float() / 4096 * 2 - 1)
+            dirs = torch.stack([dx, dy, torch.ones_like(dx)], 1)
+            dirs = (dirs / dirs.norm(dim=1, keepdim=True)).contiguous()
+            orgs = torch.zeros((n_rays, 3), device="cuda")
+            hits = torch.empty((n_rays, 10), dtype=torch.float32, device="cuda")
+            scan_flag = pt._abi.FLAG_SCAN_BVH if dscene.scan == "bvh" else 0
+            dscene.trace(orgs.data_ptr(), dirs.data_ptr(), n_rays, hits.data_ptr(), scan_flag, stream)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dscene.trace(orgs.data_ptr(), dirs.data_ptr(), n_rays, hits.data_ptr(), scan_flag, stream)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            gbs = 64.0 * n_rays / ms / 1e6
+            line["trace_rays"] = {
+                "kernel": "pt_trace_kernel", "rays": n_rays, "ms": ms, "value": n_rays / ms / 1e3,
+                "unit": "Mray/s", "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
+                                               "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                               "bytes_per_ray": 64},
+                "note": "ptgpu_trace_rays_device, eye rays of a 4096x4096 image; not part of `value`"}
+            del dirs, orgs, hits, ix, dx, dy
         if world == 1 and not args.no_cpu_baseline:
             host_frame = frame.cpu().numpy()
             base_line, rmse = cpu_baseline(pt, scene, cfg, lambda rows: host_frame[rows])
