@@ -887,8 +887,14 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         // (store_rgb8_block; 192 bytes for k <= 4) and its statistics as one
         // atomic.  Larger workgroups cost time (C2, k = 8: 62.1 ms at 64..256
         // work-items, 66.4 at 512).
+        // (a launch of less than two rounds of waves keeps single-wave
+        // workgroups, which spread better: the 256x256 C1 frame 0.054 vs 0.063 ms)
         const uint32_t wanted_block = std::min(256u, 64u * a.lanes_per_pixel);
-        if (a.lanes_per_pixel > 1u && p->block_threads == 0u && wanted_block > block &&
+        const uint64_t launch_waves = (npix * a.lanes_per_pixel + 63u) / 64u;
+        DeviceScratch *dev = nullptr;
+        const bool large = scratch_for_current_device(&dev) == PTGPU_OK && dev->max_waves > 0 &&
+                           launch_waves >= 2ull * dev->max_waves;
+        if (a.lanes_per_pixel > 1u && p->block_threads == 0u && wanted_block > block && large &&
             pt::megakernel_lds_bytes(a, wanted_block, false) <= 64u * 1024u)
             owner_block = wanted_block;
     };
