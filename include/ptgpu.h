@@ -137,7 +137,7 @@ typedef struct ptgpu_params {
                                regeneration; 64 = sample-synchronous waves.
                                In the sample queue with resumable BVH walks:
                                lanes that must wait before the wave serves
-                               them (0 = 28) */
+                               them (0 = 32) */
     uint32_t lanes_per_pixel; /* scheduling only, never changes the image:
                                lanes of a wavefront sharing one pixel's
                                samples in the pixel-owner schedule (the sum

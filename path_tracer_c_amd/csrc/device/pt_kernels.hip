@@ -978,8 +978,10 @@ __global__ void __launch_bounds__(1024)
 // pt_samplekernel; only the order in which the device gets the work done
 // differs, so the image is the same.
 // ---------------------------------------------------------------------------
+// (five waves per SIMD: 96 VGPRs; the kernel wants ~100 and is measurably
+// slower at the four waves that would give it)
 template <bool kLds>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)))
     pt_streamkernel(const LaunchArgs a, const F4 *__restrict__ scene_geom,
                     const F4 *__restrict__ scene_tri,
                     const F4 *__restrict__ scene_mat,
@@ -1021,6 +1023,7 @@ __global__ void __launch_bounds__(1024)
     walk.min_index = 0u;
     Hit hit = Hit{-1.0f, -1};
     uint32_t rays = 0, iters = 0, done = 0;
+    uint32_t shared = 0; // segments whose hit came from the primary-hit table
 #ifdef PT_BVH_PROFILE
     uint32_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #else
@@ -1041,28 +1044,45 @@ __global__ void __launch_bounds__(1024)
             __ballot(st == kHit || st == kParked || (st == kFree && !cursor.dry));
         if (walking == 0ull || (uint32_t)__popcll(waiting) >= a.settle_lanes) {
             // ---- service -----------------------------------------------------------
-            PT_BVH_COUNT(6, st == kHit);
-            if (st == kHit) { // one recursion level of incident_light
-                advance_path<2>(w.rec, a, w.stack, nthreads, w.queue, sky, p, true, hit);
-                st = p.live ? kFresh : kParked;
-            }
-            if (st == kParked) {
-                const V3 sample = unwind_path(w.rec, w.stack, nthreads, p);
-                out[out_index] = make_float4(sample.x, sample.y, sample.z, 0.0f);
-                p.parked = false;
-                st = kFree;
-                ++done;
-            }
-            // refill free lanes from the wave's chunk (as pt_samplekernel does)
-            unsigned long long free_mask = __ballot(st == kFree);
-            while (free_mask != 0ull && !cursor.dry) {
-                uint32_t sample, j;
-                if (take_task(cursor, a, chunk_counter, free_mask, st == kFree, lane, sample, j) &&
-                    j < npix) {
-                    st = kFresh;
-                    start_path(a, j, sample, p, out_index);
+            // (twice over when the refill has handed out enough tasks that
+            // start at a known primary hit: they are shaded at once instead
+            // of idling until the next service)
+#pragma nounroll
+            for (int round = 0; round < 2; ++round) {
+                PT_BVH_COUNT(6, st == kHit);
+                if (st == kHit) { // one recursion level of incident_light
+                    advance_path<2>(w.rec, a, w.stack, nthreads, w.queue, sky, p, true, hit);
+                    st = p.live ? kFresh : kParked;
                 }
-                free_mask = __ballot(st == kFree);
+                if (st == kParked) {
+                    const V3 sample = unwind_path(w.rec, w.stack, nthreads, p);
+                    out[out_index] = make_float4(sample.x, sample.y, sample.z, 0.0f);
+                    p.parked = false;
+                    st = kFree;
+                    ++done;
+                }
+                // refill free lanes from the wave's chunk (as pt_samplekernel does)
+                unsigned long long free_mask = __ballot(st == kFree);
+                while (free_mask != 0ull && !cursor.dry) {
+                    uint32_t sample, j;
+                    if (take_task(cursor, a, chunk_counter, free_mask, st == kFree, lane, sample, j) &&
+                        j < npix) {
+                        st = kFresh;
+                        start_path(a, j, sample, p, out_index);
+                        if (a.primary_hits != nullptr) { // the first segment's hit is known
+                            const float2 known = reinterpret_cast<const float2 *>(a.primary_hits)[j];
+                            hit.distance = known.x;
+                            hit.object = __builtin_bit_cast(int, known.y);
+                            st = kHit;
+                            ++rays;
+                            ++shared;
+                        }
+                    }
+                    free_mask = __ballot(st == kFree);
+                }
+                if (a.primary_hits == nullptr ||
+                    (uint32_t)__popcll(__ballot(st == kHit)) < a.reshade_lanes)
+                    break;
             }
             // every new ray starts its walk (a poisoned one gets the
             // reference's sequential scan at once, see closest_hit_bvh)
@@ -1091,7 +1111,42 @@ __global__ void __launch_bounds__(1024)
         for (int k = 0; k < 12; ++k)
             atomicAdd(&g_bvh_profile[k], (unsigned long long)prof[k]);
 #endif
-    count_block(a.counters, w.tally, rays, rays, done, iters, tid, nthreads);
+    count_block(a.counters, w.tally, rays, rays - shared, done, iters, tid, nthreads);
+}
+
+// The closest hit of every pixel's primary ray, once per frame.  The reference
+// sends the same un-jittered ray for every sample of a pixel
+// (src/renderer.c:96-107), so pt_streamkernel can start each (pixel, sample)
+// task at that hit instead of walking the hierarchy again -- a third of
+// configuration 5's segments.  Eye rays of neighbouring pixels walk alike, so
+// the whole-walk form is at its best here.
+__global__ void __launch_bounds__(256)
+    pt_primary_kernel(const LaunchArgs a, float2 *__restrict__ primary_hits) {
+    extern __shared__ uint4 lds_dyn[];
+    const uint32_t npix = a.num_rows * a.framew;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    SceneRecords rec;
+    rec.geom = a.scene.geom;
+    rec.tri = a.scene.tri;
+    rec.mat = a.scene.mat;
+    rec.meta = a.scene.meta;
+    rec.link = a.scene.link;
+    rec.n_obj = a.scene.n_obj;
+    rec.bvh_nodes = a.scene.bvh_nodes;
+    rec.bvh_order = a.scene.bvh_order;
+    rec.bvh_unbounded = a.scene.bvh_unbounded;
+    rec.n_nodes = a.scene.n_nodes;
+    rec.n_unbounded = a.scene.n_unbounded;
+    rec.bvh_root = a.scene.bvh_root;
+    rec.last_sphere = a.scene.last_sphere;
+    ScreenQueue queue;
+    queue.slot = reinterpret_cast<uint32_t *>(lds_dyn) + threadIdx.x;
+    queue.stride = blockDim.x;
+    queue.stack = queue.slot + kScreenQueue * blockDim.x;
+    const PixelSite ps = pixel_site(a, j < npix ? j : 0u);
+    const Hit h = closest_hit_bvh(rec, splat(0.0f), ps.d0, queue);
+    if (j < npix)
+        primary_hits[j] = make_float2(h.distance, __builtin_bit_cast(float, h.object));
 }
 
 // Adds the `spp` buffered samples of each pixel, in sample order, onto the
@@ -1397,6 +1452,17 @@ static hipError_t launch_sample_dispatch(const LaunchArgs &a, uint32_t grid, uin
     return a.scene_in_lds
                ? launch_sample_variant<true, 0>(a, grid, block, lds, stream)
                : launch_sample_variant<false, 0>(a, grid, block, lds, stream);
+}
+
+hipError_t launch_primary(const LaunchArgs &a, float *primary_hits, hipStream_t stream) {
+    const uint64_t npix = (uint64_t)a.num_rows * a.framew;
+    if (npix == 0)
+        return hipSuccess;
+    const uint32_t grid = (uint32_t)((npix + 255u) / 256u);
+    const size_t lds = (size_t)4 * 256u * (kScreenQueue + a.scene.bvh_depth + 2u);
+    hipLaunchKernelGGL(pt_primary_kernel, dim3(grid), dim3(256), lds, stream, a,
+                       reinterpret_cast<float2 *>(primary_hits));
+    return hipGetLastError();
 }
 
 hipError_t launch_sum(const LaunchArgs &a, hipStream_t stream) {

@@ -28,6 +28,8 @@ hipError_t launch_megakernel(const LaunchArgs &a, uint32_t block, bool tree,
 hipError_t launch_samplekernel(const LaunchArgs &a, uint32_t block,
                                uint32_t max_waves, hipStream_t stream);
 hipError_t launch_sum(const LaunchArgs &a, hipStream_t stream);
+// Closest hit of each local pixel's primary ray (BVH scan): 8 bytes per pixel.
+hipError_t launch_primary(const LaunchArgs &a, float *primary_hits, hipStream_t stream);
 hipError_t launch_resolve(const float *accum, uint8_t *frame, uint64_t npixels,
                           hipStream_t stream);
 // scan: 0 plain, 1 screened linear, 2 BVH (the scene must have a hierarchy)

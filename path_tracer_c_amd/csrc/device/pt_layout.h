@@ -108,11 +108,14 @@ struct LaunchArgs {
     uint32_t chunk_batch;   // sample queue: chunks a wave reserves per atomic
     uint32_t stream_walks;  // sample queue + BVH scan: resumable walks (pt_streamkernel)
     uint32_t walk_budget;   // ... inner-node steps per quantum
+    uint32_t reshade_lanes; // ... second shading round of a service stage from this many lanes
     uint32_t lanes_per_pixel; // pixel-owner kernel: 1, or 2..64 (power of two) lanes
                               // sharing a pixel's samples (small row sets)
     // sample-queue mode (pt_samplekernel / pt_sum_kernel)
     float *sample_buf;       // float4 per task: [sample][npix_pad]
     uint32_t *chunk_counter; // next chunk of 64 tasks; zeroed before a launch
+    const float *primary_hits; // (distance, object) per local pixel of the row set:
+                               // the closest hit of its primary ray, or null
     uint32_t npix_pad;       // pixels of the row set, rounded up to 64
     uint32_t chunks_per_sample; // npix_pad / 64
     uint32_t num_chunks;     // spp * chunks_per_sample

@@ -537,7 +537,10 @@ namespace {
 // Stream kernel (sample queue + BVH scan): a service stage runs when this many
 // lanes of a wave wait for one, and a walk quantum takes this many inner-node
 // steps at most (PTGPU_WALK_BUDGET overrides, for tuning).
-constexpr uint32_t kStreamServiceLanes = 28;
+constexpr uint32_t kStreamServiceLanes = 32;
+// ... and shades a second time within the stage when the refill has handed out
+// this many tasks that start at a known primary hit (C5, 32 spp: 20.4 -> 19.4 ms)
+constexpr uint32_t kStreamReshadeLanes = 4;
 uint32_t stream_walk_budget() {
     static const uint32_t budget = [] {
         uint32_t v = 4u;
@@ -648,6 +651,7 @@ int prepare_launch(const ptgpu_scene *s, size_t framew, size_t frameh,
     a->lanes_per_pixel = 1u; // render_common decides
     a->stream_walks = 0u;
     a->chunk_batch = 1u; // the launcher decides
+    a->primary_hits = nullptr;
     a->walk_budget = 0u;
     if (p->settle_lanes > 64u)
         return fail(PTGPU_ERR_INVALID, "settle_lanes must be 0..64");
@@ -687,6 +691,8 @@ struct DeviceScratch {
     size_t sample_bytes = 0;
     float *accum = nullptr;     // float4 per pixel (fused renders)
     size_t accum_bytes = 0;
+    float *primary = nullptr;   // (distance, object) per pixel: primary-ray hits
+    size_t primary_bytes = 0;
     uint32_t *chunk_counters = nullptr; // ring of kCounterRing counters
     uint32_t next_counter = 0;
     uint32_t max_waves = 0;     // waves the device keeps resident
@@ -949,6 +955,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
     // waves into the buffer, then added to the accumulator in sample order;
     // the pass that completes the frame also writes RGB8.
     const uint32_t npix_pad = (uint32_t)((npix + 63u) & ~(uint64_t)63u);
+    bool primary_ready = false; // sc->primary holds this call's primary-ray hits
     auto queue_pass = [&](uint32_t scan, uint32_t want) -> int {
         uint64_t per_pass = scratch_budget_bytes() / ((uint64_t)npix_pad * 16u);
         if (per_pass < 1)
@@ -972,10 +979,24 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         q.chunk_counter = sc->chunk_counters + (sc->next_counter++ % kCounterRing);
         PT_TRY_HIP(hipMemsetAsync(q.chunk_counter, 0, sizeof(uint32_t), stream));
         if (scan == 2u && !(p->flags & PTGPU_FLAG_WHOLE_WALKS)) {
+            // every sample of a pixel starts with the same primary ray: its
+            // hit is found once per call and handed to the tasks
+            if (a.share_primary && !primary_ready) {
+                grc = grow(&sc->primary, &sc->primary_bytes, (size_t)npix * 8u);
+                if (grc != PTGPU_OK)
+                    return grc;
+                hipError_t pe = pt::launch_primary(a, sc->primary, stream);
+                if (pe != hipSuccess)
+                    return fail_hip(pe, "primary-hit launch");
+                primary_ready = true;
+            }
+            if (a.share_primary)
+                q.primary_hits = sc->primary;
             // resumable walks: settle_lanes = lanes waiting before a service stage
             q.stream_walks = 1u;
             q.settle_lanes = p->settle_lanes ? p->settle_lanes : kStreamServiceLanes;
             q.walk_budget = stream_walk_budget();
+            q.reshade_lanes = kStreamReshadeLanes;
         }
         hipError_t e = pt::launch_samplekernel(q, block, sc->max_waves, stream);
         if (e != hipSuccess)
@@ -1543,9 +1564,12 @@ int ptgpu_release_scratch(void) {
         (void)hipFree(sc.samples);
     if (sc.accum)
         (void)hipFree(sc.accum);
+    if (sc.primary)
+        (void)hipFree(sc.primary);
     sc.samples = nullptr;
     sc.accum = nullptr;
-    sc.sample_bytes = sc.accum_bytes = 0;
+    sc.primary = nullptr;
+    sc.sample_bytes = sc.accum_bytes = sc.primary_bytes = 0;
     return PTGPU_OK;
 }
 

@@ -763,6 +763,30 @@ def test_host_code_under_sanitizers_with_real_kernels(gpu, tmp_path):
     assert pixels.mean() > 10                      # a real frame, not a black one
 
 
+def test_primary_hits_are_shared_in_the_stream_kernel_and_accounted(gpu, oracle):
+    """Sample queue + BVH scan: every task starts at its pixel's primary hit,
+    found once per call (pt_primary_kernel).  Same frame; `rays` still counts
+    every segment, `scans` one less per sample; with
+    PTGPU_FLAG_NO_PRIMARY_SHARE every segment is walked."""
+    w, h, spp = 96, 54, 6
+    with gpu.HostScene(5) as s:
+        ref, rays = oracle.render_rows(s, w, h, spp=spp, max_bounces=8, seed=4)
+        gpu.host.reset_stats()
+        shared = gpu.render_frame(s, w, h, spp=spp, max_bounces=8, seed=4, flags=0x500)
+        st_shared = gpu.host.read_stats()
+        gpu.host.reset_stats()
+        walked = gpu.render_frame(s, w, h, spp=spp, max_bounces=8, seed=4, flags=0x700)
+        st_walked = gpu.host.read_stats()
+        # rows of a shard start at their own primary hits too
+        part = gpu.render_frame(s, w, h, spp=spp, max_bounces=8, seed=4, flags=0x500,
+                                row_begin=7, num_rows=20)
+    assert np.array_equal(shared, ref) and np.array_equal(walked, ref)
+    assert np.array_equal(part[7:27], ref[7:27])
+    assert st_shared.rays == rays and st_walked.rays == rays
+    assert st_walked.scans == rays
+    assert st_shared.rays - st_shared.scans == w * h * spp
+
+
 def _random_scene(gpu, rng, branching):
     """A hostile random scene: any object count, scales from 1e-3 to 1e4,
     zero / huge / negative radii, camera inside spheres, slivers, roughness

@@ -16,6 +16,7 @@ with pt.HostScene(c['scene']) as s, pt.DeviceScene(s) as d:
     p = pt.make_params(spp=spp, max_bounces=c['max_bounces'], seed=1, flags=0x480, lanes_per_pixel=1)
     d.render(ref.data_ptr(), w, h, p, st); torch.cuda.synchronize()
     for name, flags, settle, block in [("whole walks", 0xD00, 0, 0)] + [(f"stream, service at {t}", 0x500, t, 0) for t in (16, 24, 32)] + \
+            [(f"stream, every ray walked, service at {t}", 0x700, t, 0) for t in (24, 32)] + \
             [(f"stream, block {b}", 0x500, 24, b) for b in (128, 256)] + [(f"stream+LDS, block {b}", 0x540, 24, b) for b in (512, 1024)]:
         p = pt.make_params(spp=spp, max_bounces=c['max_bounces'], seed=1, flags=flags, settle_lanes=settle, block_threads=block)
         d.render(out.data_ptr(), w, h, p, st); torch.cuda.synchronize()
@@ -26,4 +27,4 @@ with pt.HostScene(c['scene']) as s, pt.DeviceScene(s) as d:
         e1.record(); torch.cuda.synchronize()
         stt = pt.host.read_stats()
         ms = e0.elapsed_time(e1) / 2
-        print(f"{name:24s} {ms:8.2f} ms  {stt.rays / 2 / ms / 1e6:6.2f} Gray/s  same {bool(torch.equal(out, ref))}", flush=True)
+        print(f"{name:40s} {ms:8.2f} ms  {stt.rays / 2 / ms / 1e6:6.2f} Gray/s  same {bool(torch.equal(out, ref))}", flush=True)
