@@ -190,6 +190,7 @@ struct ptgpu_scene {
     // the pixel-owner kernel may put several lanes on a pixel freely.
     mutable std::atomic<int> full_depth{-1};
     uint64_t content_hash = 0; // of the uploaded records: key of the choice memo
+    uint64_t serial = 0;       // unique per upload (never reused): identifies cached tables
 };
 
 namespace {
@@ -389,6 +390,8 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
     }
     h->blob_bytes = blob.size();
     h->content_hash = fnv1a64(blob.data(), blob.size());
+    static std::atomic<uint64_t> next_serial{1};
+    h->serial = next_serial.fetch_add(1);
     const pt::F4 *dbase = reinterpret_cast<const pt::F4 *>(h->blob);
     h->desc.geom = dbase;
     h->desc.tri = dbase + n_obj;
@@ -686,6 +689,19 @@ void count_launch() {
 namespace {
 
 // Per-device scratch of the sample-queue mode, grown on demand.
+// What a primary-hit table was computed for: the upload (by serial, exact),
+// the camera and the row set.
+struct PrimaryView {
+    uint64_t scene_serial = 0;
+    uint32_t framew = 0, frameh = 0, row_begin = 0, num_rows = 0, tile_rows = 0, tile_stride = 0;
+    uint32_t tan_half_fov_bits = 0;
+    bool operator==(const PrimaryView &o) const {
+        return scene_serial == o.scene_serial && framew == o.framew && frameh == o.frameh &&
+               row_begin == o.row_begin && num_rows == o.num_rows && tile_rows == o.tile_rows &&
+               tile_stride == o.tile_stride && tan_half_fov_bits == o.tan_half_fov_bits;
+    }
+};
+
 struct DeviceScratch {
     float *samples = nullptr;   // float4 per task of one pass
     size_t sample_bytes = 0;
@@ -693,6 +709,7 @@ struct DeviceScratch {
     size_t accum_bytes = 0;
     float *primary = nullptr;   // (distance, object) per pixel: primary-ray hits
     size_t primary_bytes = 0;
+    PrimaryView primary_view;   // what `primary` holds (serial 0: nothing)
     uint32_t *chunk_counters = nullptr; // ring of kCounterRing counters
     uint32_t next_counter = 0;
     uint32_t max_waves = 0;     // waves the device keeps resident
@@ -982,12 +999,21 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
             // every sample of a pixel starts with the same primary ray: its
             // hit is found once per call and handed to the tasks
             if (a.share_primary && !primary_ready) {
-                grc = grow(&sc->primary, &sc->primary_bytes, (size_t)npix * 8u);
-                if (grc != PTGPU_OK)
-                    return grc;
-                hipError_t pe = pt::launch_primary(a, sc->primary, stream);
-                if (pe != hipSuccess)
-                    return fail_hip(pe, "primary-hit launch");
+                // (kept from call to call: progressive passes of one view find
+                // the table of the previous pass)
+                const PrimaryView view{s->serial, a.framew, a.frameh, a.row_begin, a.num_rows,
+                                       a.tile_rows, a.tile_stride,
+                                       __builtin_bit_cast(uint32_t, a.tan_half_fov)};
+                if (!(sc->primary_view == view) || sc->primary_bytes < (size_t)npix * 8u) {
+                    sc->primary_view = PrimaryView{};
+                    grc = grow(&sc->primary, &sc->primary_bytes, (size_t)npix * 8u);
+                    if (grc != PTGPU_OK)
+                        return grc;
+                    hipError_t pe = pt::launch_primary(a, sc->primary, stream);
+                    if (pe != hipSuccess)
+                        return fail_hip(pe, "primary-hit launch");
+                    sc->primary_view = view;
+                }
                 primary_ready = true;
             }
             if (a.share_primary)
@@ -1570,6 +1596,7 @@ int ptgpu_release_scratch(void) {
     sc.accum = nullptr;
     sc.primary = nullptr;
     sc.sample_bytes = sc.accum_bytes = sc.primary_bytes = 0;
+    sc.primary_view = PrimaryView{};
     return PTGPU_OK;
 }
 

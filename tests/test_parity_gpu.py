@@ -787,6 +787,35 @@ def test_primary_hits_are_shared_in_the_stream_kernel_and_accounted(gpu, oracle)
     assert st_shared.rays - st_shared.scans == w * h * spp
 
 
+def test_cached_primary_hits_follow_the_view(gpu, oracle, torch_cuda):
+    """The primary-hit table is kept between calls of one view (progressive
+    passes) and redone when the scene, the camera or the row set changes."""
+    torch = torch_cuda
+    kw = dict(max_bounces=6, seed=9)
+    with gpu.HostScene(5) as s, gpu.DeviceScene(s) as d, gpu.DeviceScene(s) as d2:
+        views = [(80, 45, {}), (80, 45, dict(row_begin=10, num_rows=20)), (64, 36, {}),
+                 (80, 45, dict(fov_rad=1.0)), (80, 45, {})]
+        for dev in (d, d2, d):                               # another upload of the same scene in between
+            for w, h, extra in views:
+                got = render_device(gpu, torch, dev, w, h, spp=3, flags=0x500, **kw, **extra)
+                fov = extra.get("fov_rad")
+                ref, _ = oracle.render_rows(s, w, h, spp=3, **kw, **({"fov_rad": fov} if fov else {}))
+                lo = extra.get("row_begin", 0); n = extra.get("num_rows", h)
+                assert np.array_equal(got[lo:lo + n], ref[lo:lo + n]), (w, h, extra)
+        # progressive passes of one view: the table of the first pass serves the others
+        w, h = 80, 45
+        st = torch.cuda.current_stream().cuda_stream
+        acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+        for i in range(4):
+            d.accumulate(acc.data_ptr(), w, h, gpu.make_params(spp=2, sample_offset=2 * i, flags=0x500, **kw), st)
+        gpu._abi.check(gpu.lib().ptgpu_resolve_device(C.c_void_p(acc.data_ptr()), C.c_void_p(out.data_ptr()),
+                                                      w * h, C.c_void_p(st)))
+        torch.cuda.synchronize()
+        ref, _ = oracle.render_rows(s, w, h, spp=8, **kw)
+        assert np.array_equal(out.cpu().numpy(), ref)
+
+
 def _random_scene(gpu, rng, branching):
     """A hostile random scene: any object count, scales from 1e-3 to 1e4,
     zero / huge / negative radii, camera inside spheres, slivers, roughness
