@@ -391,8 +391,9 @@ struct Frame {
     uint32_t awaiting_transmit; // 0: child in flight is the reflection
 };
 
-__device__ void run_tree(const SceneRecords &rec, const LaunchArgs &a, V3 d0,
-                         uint32_t pixel, uint32_t spp, V3 sky, V3 &sum,
+template <int kScan>
+__device__ void run_tree(const SceneRecords &rec, const LaunchArgs &a, const ScreenQueue queue,
+                         V3 d0, uint32_t pixel, uint32_t spp, V3 sky, V3 &sum,
                          uint32_t &rays, uint32_t &iters) {
     Frame frames[kTreeFrames];
     for (uint32_t s = 0; s < spp; ++s) {
@@ -413,7 +414,7 @@ __device__ void run_tree(const SceneRecords &rec, const LaunchArgs &a, V3 d0,
                     continue;
                 }
                 ++rays;
-                const Hit h = closest_hit(rec, o, d);
+                const Hit h = scan_scene<kScan>(rec, o, d, queue);
                 if (h.distance < 0.0f) {
                     ret = sky;
                     state = 1;
@@ -775,7 +776,7 @@ __global__ void __launch_bounds__(1024) pt_megakernel(const LaunchArgs a) {
     const uint32_t spp = valid ? a.spp : 0u;
     uint32_t samples_done = owner ? spp : 0u;
     if (kTree) {
-        run_tree(w.rec, a, ps.d0, ps.pixel, spp, sky, sum, rays, iters);
+        run_tree<kScan>(w.rec, a, w.queue, ps.d0, ps.pixel, spp, sky, sum, rays, iters);
         scans = rays;
     } else if (k == 1u) {
         run_paths<kScan>(w.rec, a, w.stack, nthreads, w.queue, ps.d0, ps.pixel,
@@ -1353,16 +1354,17 @@ size_t megakernel_lds_bytes(const LaunchArgs &a, uint32_t block, bool tree) {
     size_t bytes = (size_t)16 * (block / 64u); // tally records (count_block)
     if (a.scene_in_lds) {
         bytes += scene_lds_bytes(a.scene.n_obj, a.scene.n_tri, a.scene.n_mat);
-        if (a.screened == 2u && !tree)
+        if (a.screened == 2u)
             bytes += (size_t)64 * a.scene.n_nodes;
     }
-    if (!tree) {
-        bytes += ((size_t)2 * block * ((size_t)a.max_bounces + 1u) + 15u) & ~(size_t)15u;
-        if (a.screened)
-            bytes += (size_t)4 * block * kScreenQueue;
-        if (a.screened == 2u)
-            bytes += (size_t)4 * block * (a.scene.bvh_depth + 2u);
-    }
+    // (the branching kernel keeps its frames in private memory and leaves the
+    // bounce stack unused, but shares the layout)
+    (void)tree;
+    bytes += ((size_t)2 * block * ((size_t)a.max_bounces + 1u) + 15u) & ~(size_t)15u;
+    if (a.screened)
+        bytes += (size_t)4 * block * kScreenQueue;
+    if (a.screened == 2u)
+        bytes += (size_t)4 * block * (a.scene.bvh_depth + 2u);
     return (bytes + 15u) & ~(size_t)15u;
 }
 
@@ -1374,6 +1376,14 @@ hipError_t launch_megakernel(const LaunchArgs &a, uint32_t block, bool tree,
     const uint64_t lanes = npix * (tree || a.lanes_per_pixel == 0 ? 1u : a.lanes_per_pixel);
     const uint32_t grid = (uint32_t)((lanes + block - 1) / block);
     const size_t lds = megakernel_lds_bytes(a, block, tree);
+    if (tree && a.screened == 2u)
+        return a.scene_in_lds
+                   ? launch_variant<true, true, 2>(a, grid, block, lds, stream)
+                   : launch_variant<false, true, 2>(a, grid, block, lds, stream);
+    if (tree && a.screened == 1u)
+        return a.scene_in_lds
+                   ? launch_variant<true, true, 1>(a, grid, block, lds, stream)
+                   : launch_variant<false, true, 1>(a, grid, block, lds, stream);
     if (tree)
         return a.scene_in_lds
                    ? launch_variant<true, true, 0>(a, grid, block, lds, stream)

@@ -859,7 +859,9 @@ def test_randomised_scenes_match_the_oracle(gpu, oracle, branching):
             w, h = int(rng.integers(8, 70)), int(rng.integers(5, 40))
             spp = int(rng.integers(1, 5))
             b = int(rng.integers(0, 11 if not branching else 5))
-            flags = int(rng.choice([0, 0x40, 0x100, 0x20, 0x10, 0x140])) if not branching else int(rng.choice([0, 0x40]))
+            flags = int(rng.choice([0, 0x40, 0x100, 0x20, 0x10, 0x140])) if not branching else int(rng.choice([0, 0x40, 0x10, 0x20]))
+            if branching and s.num_objects >= 64 and trial % 3 == 0:
+                flags |= 0x400                           # the branching kernel walks the hierarchy too
             if not branching and s.num_objects >= 64 and trial % 2:
                 # hierarchy scan: default schedule, pixel owner, queue with
                 # resumable walks (+ LDS copy), queue with whole walks
