@@ -506,6 +506,25 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
     return v;
 }
 
+// The scene as uploaded, read from global memory (constant cache / L2).
+__device__ __forceinline__ SceneRecords records_in_global_memory(const SceneDesc &scene) {
+    SceneRecords rec;
+    rec.geom = scene.geom;
+    rec.tri = scene.tri;
+    rec.mat = scene.mat;
+    rec.meta = scene.meta;
+    rec.link = scene.link;
+    rec.n_obj = scene.n_obj;
+    rec.bvh_nodes = scene.bvh_nodes;
+    rec.bvh_order = scene.bvh_order;
+    rec.bvh_unbounded = scene.bvh_unbounded;
+    rec.n_nodes = scene.n_nodes;
+    rec.n_unbounded = scene.n_unbounded;
+    rec.bvh_root = scene.bvh_root;
+    rec.last_sphere = scene.last_sphere;
+    return rec;
+}
+
 // ---- pieces shared by the kernels ---------------------------------------------
 struct WorkgroupScene {
     SceneRecords rec;
@@ -1126,20 +1145,7 @@ __global__ void __launch_bounds__(256)
     extern __shared__ uint4 lds_dyn[];
     const uint32_t npix = a.num_rows * a.framew;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    SceneRecords rec;
-    rec.geom = a.scene.geom;
-    rec.tri = a.scene.tri;
-    rec.mat = a.scene.mat;
-    rec.meta = a.scene.meta;
-    rec.link = a.scene.link;
-    rec.n_obj = a.scene.n_obj;
-    rec.bvh_nodes = a.scene.bvh_nodes;
-    rec.bvh_order = a.scene.bvh_order;
-    rec.bvh_unbounded = a.scene.bvh_unbounded;
-    rec.n_nodes = a.scene.n_nodes;
-    rec.n_unbounded = a.scene.n_unbounded;
-    rec.bvh_root = a.scene.bvh_root;
-    rec.last_sphere = a.scene.last_sphere;
+    const SceneRecords rec = records_in_global_memory(a.scene);
     ScreenQueue queue;
     queue.slot = reinterpret_cast<uint32_t *>(lds_dyn) + threadIdx.x;
     queue.stride = blockDim.x;
@@ -1236,20 +1242,7 @@ __global__ void __launch_bounds__(256)
     // end trace a dummy ray and store nothing
     const bool valid = i < n;
     const uint64_t at = valid ? i : 0;
-    SceneRecords rec;
-    rec.geom = scene.geom;
-    rec.tri = scene.tri;
-    rec.mat = scene.mat;
-    rec.meta = scene.meta;
-    rec.link = scene.link;
-    rec.n_obj = scene.n_obj;
-    rec.bvh_nodes = scene.bvh_nodes;
-    rec.bvh_order = scene.bvh_order;
-    rec.bvh_unbounded = scene.bvh_unbounded;
-    rec.n_nodes = scene.n_nodes;
-    rec.n_unbounded = scene.n_unbounded;
-    rec.bvh_root = scene.bvh_root;
-    rec.last_sphere = scene.last_sphere;
+    const SceneRecords rec = records_in_global_memory(scene);
     ScreenQueue queue;
     queue.slot = reinterpret_cast<uint32_t *>(lds_dyn) + threadIdx.x;
     queue.stride = blockDim.x;
