@@ -3,7 +3,7 @@ import sys, hashlib
 sys.path.insert(0, '.')
 import torch
 import path_tracer_c_amd as pt
-for cfg, spp, n, flagsets in ((2, 256, 20, (0, 0x100, 0x40)), (5, 32, 8, (0, 0x80, 0x20))):
+for cfg, spp, n, flagsets in ((2, 256, 12, (0, 0x100, 0x40, 0x200)), (5, 32, 8, (0, 0x80, 0x20, 0x500, 0x700, 0xD00))):
     c = pt.CONFIGS[cfg]; w, h = c['width'], c['height']
     with pt.HostScene(c['scene']) as s, pt.DeviceScene(s) as d:
         digests = set()
