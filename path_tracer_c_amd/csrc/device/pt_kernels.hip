@@ -136,7 +136,7 @@ __device__ __forceinline__ V3 shade_level(const F4 m0, const F4 m1, V3 child) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");  \
     __builtin_amdgcn_sched_barrier(0)
 #define PT_STAMP_ADD(field, later, earlier) (field) += (later) - (earlier)
-__device__ unsigned long long g_stamps[4];
+__device__ unsigned long long g_stamps[8];
 #else
 #define PT_STAMP(var)
 #define PT_STAMP_ADD(field, later, earlier)
@@ -1044,11 +1044,40 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
     Hit hit = Hit{-1.0f, -1};
     uint32_t rays = 0, iters = 0, done = 0;
     uint32_t shared = 0; // segments whose hit came from the primary-hit table
+#ifdef PT_STAMPS
+    unsigned long long t_walk = 0, t_shade = 0, t_settle = 0, t_refill = 0;
+    PT_STAMP(k_begin);
+#endif
 #ifdef PT_BVH_PROFILE
     uint32_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #else
     uint32_t *const prof = nullptr;
 #endif
+
+    // every new ray starts its walk (a poisoned one gets the reference's
+    // sequential scan at once, see closest_hit_bvh)
+    auto begin_walks = [&]() {
+        if (st == kFresh) {
+            ++rays;
+            if (ray_is_poisoned(p.o, p.d)) {
+#ifdef PT_BVH_PROFILE
+                atomicAdd(&g_bvh_profile[9], 1ull);
+#endif
+                hit = poisoned_hit(w.rec, p.o, p.d);
+                st = kHit;
+            } else {
+                bvh_walk_first(w.rec, w.queue, p.o, p.d, walk);
+                st = kWalk;
+            }
+        }
+    };
+    // one recursion level of incident_light for the lanes whose walk has ended
+    auto shade_hits = [&]() {
+        if (st == kHit) {
+            advance_path<2>(w.rec, a, w.stack, nthreads, w.queue, sky, p, true, hit);
+            st = p.live ? kFresh : kParked;
+        }
+    };
 
     for (;;) {
         if (st == kWalk && bvh_walk_idle(w.queue, walk)) {
@@ -1062,7 +1091,19 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
         const unsigned long long walking = __ballot(st == kWalk);
         const unsigned long long waiting =
             __ballot(st == kHit || st == kParked || (st == kFree && !cursor.dry));
-        if (walking == 0ull || (uint32_t)__popcll(waiting) >= a.settle_lanes) {
+        const bool full_service = walking == 0ull || (uint32_t)__popcll(waiting) >= a.settle_lanes;
+        if (!full_service && (uint32_t)__popcll(__ballot(st == kHit)) >= a.shade_lanes) {
+            // ---- quick stage: finished walks are shaded and their next rays start,
+            // which is most of what waits (3.4 segments per path on C5); ended
+            // paths and free lanes wait for a full service
+            PT_STAMP(sq0);
+            shade_hits();
+            begin_walks();
+            PT_STAMP(sq1);
+            PT_STAMP_ADD(t_shade, sq1, sq0);
+            continue;
+        }
+        if (full_service) {
             // ---- service -----------------------------------------------------------
             // (twice over when the refill has handed out enough tasks that
             // start at a known primary hit: they are shaded at once instead
@@ -1070,10 +1111,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
 #pragma nounroll
             for (int round = 0; round < 2; ++round) {
                 PT_BVH_COUNT(6, st == kHit);
-                if (st == kHit) { // one recursion level of incident_light
-                    advance_path<2>(w.rec, a, w.stack, nthreads, w.queue, sky, p, true, hit);
-                    st = p.live ? kFresh : kParked;
-                }
+                PT_STAMP(sv0);
+                shade_hits();
+                PT_STAMP(sv1);
+                PT_STAMP_ADD(t_shade, sv1, sv0);
                 if (st == kParked) {
                     const V3 sample = unwind_path(w.rec, w.stack, nthreads, p);
                     out[out_index] = make_float4(sample.x, sample.y, sample.z, 0.0f);
@@ -1081,6 +1122,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
                     st = kFree;
                     ++done;
                 }
+                PT_STAMP(sv2);
+                PT_STAMP_ADD(t_settle, sv2, sv1);
                 // refill free lanes from the wave's chunk (as pt_samplekernel does)
                 unsigned long long free_mask = __ballot(st == kFree);
                 while (free_mask != 0ull && !cursor.dry) {
@@ -1100,32 +1143,35 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
                     }
                     free_mask = __ballot(st == kFree);
                 }
+                PT_STAMP(sv3);
+                PT_STAMP_ADD(t_refill, sv3, sv2);
                 if (a.primary_hits == nullptr ||
                     (uint32_t)__popcll(__ballot(st == kHit)) < a.reshade_lanes)
                     break;
             }
-            // every new ray starts its walk (a poisoned one gets the
-            // reference's sequential scan at once, see closest_hit_bvh)
-            if (st == kFresh) {
-                ++rays;
-                if (ray_is_poisoned(p.o, p.d)) {
-#ifdef PT_BVH_PROFILE
-                    atomicAdd(&g_bvh_profile[9], 1ull);
-#endif
-                    hit = poisoned_hit(w.rec, p.o, p.d);
-                    st = kHit;
-                } else {
-                    bvh_walk_first(w.rec, w.queue, p.o, p.d, walk);
-                    st = kWalk;
-                }
-            }
+            begin_walks();
             if (__ballot(st != kFree) == 0ull)
                 break; // pool dry and every lane idle
             continue;
         }
         ++iters;
+        PT_STAMP(q0);
         bvh_walk_quantum(w.rec, w.queue, p.o, p.d, st == kWalk, a.walk_budget, walk, prof);
+        PT_STAMP(q1);
+        PT_STAMP_ADD(t_walk, q1, q0);
     }
+#ifdef PT_STAMPS
+    {
+        PT_STAMP(k_end);
+        if (lane == 0u) {
+            atomicAdd(&g_stamps[0], t_walk);
+            atomicAdd(&g_stamps[1], t_shade);
+            atomicAdd(&g_stamps[2], t_settle);
+            atomicAdd(&g_stamps[3], k_end - k_begin);
+            atomicAdd(&g_stamps[4], t_refill);
+        }
+    }
+#endif
 #ifdef PT_BVH_PROFILE
     if (lane == 0u)
         for (int k = 0; k < 12; ++k)
@@ -1478,11 +1524,11 @@ hipError_t launch_sum(const LaunchArgs &a, hipStream_t stream) {
 }
 
 #ifdef PT_STAMPS
-extern "C" int ptgpu_debug_stamps(unsigned long long out[4], int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 4) != hipSuccess)
+extern "C" int ptgpu_debug_stamps(unsigned long long out[8], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8) != hipSuccess)
         return -1;
     if (reset) {
-        unsigned long long zero[4] = {0, 0, 0, 0};
+        unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof zero) != hipSuccess)
             return -1;
     }

@@ -108,6 +108,7 @@ struct LaunchArgs {
     uint32_t chunk_batch;   // sample queue: chunks a wave reserves per atomic
     uint32_t stream_walks;  // sample queue + BVH scan: resumable walks (pt_streamkernel)
     uint32_t walk_budget;   // ... inner-node steps per quantum
+    uint32_t shade_lanes;   // ... lanes with a finished walk that trigger a shading-only stage
     uint32_t reshade_lanes; // ... second shading round of a service stage from this many lanes
     uint32_t lanes_per_pixel; // pixel-owner kernel: 1, or 2..64 (power of two) lanes
                               // sharing a pixel's samples (small row sets)

@@ -544,6 +544,9 @@ constexpr uint32_t kStreamServiceLanes = 32;
 // ... and shades a second time within the stage when the refill has handed out
 // this many tasks that start at a known primary hit (C5, 32 spp: 20.4 -> 19.4 ms)
 constexpr uint32_t kStreamReshadeLanes = 4;
+// Between full services, 16 lanes with a finished walk get a shading-only stage
+// (finished walks are most of what waits; C5, 32 spp: 17.6 -> 16.7 ms)
+constexpr uint32_t kStreamShadeLanes = 16;
 uint32_t stream_walk_budget() {
     static const uint32_t budget = [] {
         uint32_t v = 4u;
@@ -1023,6 +1026,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
             q.settle_lanes = p->settle_lanes ? p->settle_lanes : kStreamServiceLanes;
             q.walk_budget = stream_walk_budget();
             q.reshade_lanes = kStreamReshadeLanes;
+            q.shade_lanes = kStreamShadeLanes;
         }
         hipError_t e = pt::launch_samplekernel(q, block, sc->max_waves, stream);
         if (e != hipSuccess)
