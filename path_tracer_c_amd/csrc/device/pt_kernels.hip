@@ -395,56 +395,46 @@ template <int kScan>
 __device__ void run_tree(const SceneRecords &rec, const LaunchArgs &a, const ScreenQueue queue,
                          V3 d0, uint32_t pixel, uint32_t spp, V3 sky, V3 &sum,
                          uint32_t &rays, uint32_t &iters) {
+    // Per lane: the recursion of incident_light as an explicit stack of frames,
+    // one sample after the other.  A pass of the outer loop has two parts:
+    //   bookkeeping  the lane returns values up its stack and picks the next
+    //                child to evaluate, until it stands before a call that
+    //                needs a ray traced (or has finished its last sample) --
+    //                cheap, lane by lane;
+    //   trace+shade  every lane that has such a call scans the scene and opens
+    //                the frame -- the expensive part, run with all of them at
+    //                once instead of whenever a lane happened to get there.
     Frame frames[kTreeFrames];
-    for (uint32_t s = 0; s < spp; ++s) {
-        uint32_t rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset + s);
-        int sp = 0; // frames in use; a call at recursion depth k has sp == k
-        V3 o = splat(0.0f), d = d0;
-        V3 ret = splat(0.0f);
-        // state: 0 = enter a call with (o, d, bounces = sp)
-        //        1 = a call returned `ret` to the frame on top
-        //        2 = top frame must now evaluate its transmission branch
-        int state = 0;
-        for (;;) {
-            ++iters;
-            if (state == 0) {
-                if ((uint32_t)sp > a.max_bounces) {
-                    ret = sky;
-                    state = 1;
+    uint32_t s = 0;
+    uint32_t rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset);
+    int sp = 0; // frames in use; a call at recursion depth k has sp == k
+    V3 o = splat(0.0f), d = d0;
+    V3 ret = splat(0.0f);
+    // state: 0 = enter a call with (o, d, bounces = sp)
+    //        1 = a call returned `ret` to the frame on top
+    //        2 = top frame must now evaluate its transmission branch
+    //        3 = all samples done
+    int state = spp != 0u ? 0 : 3;
+    for (;;) {
+        // ---- bookkeeping until a trace is due ----------------------------------
+        while (state == 1 || state == 2 || (state == 0 && (uint32_t)sp > a.max_bounces)) {
+            if (state == 0) { // the call is beyond the bounce limit: sky, no trace
+                ret = sky;
+                state = 1;
+            } else if (state == 1) {
+                if (sp == 0) { // the root call returned: the sample is complete
+                    sum = sum + clamp01(ret);
+                    ++s;
+                    if (s < spp) {
+                        rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset + s);
+                        o = splat(0.0f);
+                        d = d0;
+                        state = 0;
+                    } else {
+                        state = 3;
+                    }
                     continue;
                 }
-                ++rays;
-                const Hit h = scan_scene<kScan>(rec, o, d, queue);
-                if (h.distance < 0.0f) {
-                    ret = sky;
-                    state = 1;
-                    continue;
-                }
-                const Surface sf = surface_at(rec, o, d, h);
-                const F4 m0 = rec.mat[2 * sf.material + 0];
-                const float t = rec.mat[2 * sf.material + 1].w;
-                V3 deviation = rand_unit_sphere(rng) * m0.w;
-                Frame &f = frames[sp];
-                f.d_in = d;
-                f.normal = normalize(sf.normal + deviation);
-                f.point = sf.point;
-                f.refl = splat(0.0f);
-                f.material = sf.material;
-                f.awaiting_transmit = 0;
-                ++sp;
-                if (t < 1.0f) {
-                    Bounce b = reflect_ray(d, f.normal, f.point);
-                    o = b.origin;
-                    d = b.direction;
-                    state = 0;
-                } else {
-                    state = 2;
-                }
-                continue;
-            }
-            if (state == 1) {
-                if (sp == 0)
-                    break; // the root call returned
                 Frame &f = frames[sp - 1];
                 if (!f.awaiting_transmit) {
                     f.refl = ret;
@@ -456,11 +446,8 @@ __device__ void run_tree(const SceneRecords &rec, const LaunchArgs &a, const Scr
                 const F4 m1 = rec.mat[2 * f.material + 1];
                 V3 li = lerp(f.refl, ret, m1.w);
                 ret = xyz(m1) + li * xyz(m0);
-                --sp;
-                continue; // state stays 1: return to the parent
-            }
-            // state == 2
-            {
+                --sp; // state stays 1: return to the parent
+            } else { // state == 2
                 Frame &f = frames[sp - 1];
                 const F4 m0 = rec.mat[2 * f.material + 0];
                 const F4 m1 = rec.mat[2 * f.material + 1];
@@ -484,13 +471,42 @@ __device__ void run_tree(const SceneRecords &rec, const LaunchArgs &a, const Scr
                 }
             }
         }
-        sum = sum + clamp01(ret);
+        if (!__any(state == 0))
+            break; // every lane of the wave has finished its samples
+        // ---- trace + shade for the lanes that stand before a call -----------------
+        ++iters;
+        if (state == 0) {
+            ++rays;
+            const Hit h = scan_scene<kScan>(rec, o, d, queue);
+            if (h.distance < 0.0f) {
+                ret = sky;
+                state = 1;
+            } else {
+                const Surface sf = surface_at(rec, o, d, h);
+                const F4 m0 = rec.mat[2 * sf.material + 0];
+                const float t = rec.mat[2 * sf.material + 1].w;
+                V3 deviation = rand_unit_sphere(rng) * m0.w;
+                Frame &f = frames[sp];
+                f.d_in = d;
+                f.normal = normalize(sf.normal + deviation);
+                f.point = sf.point;
+                f.refl = splat(0.0f);
+                f.material = sf.material;
+                f.awaiting_transmit = 0;
+                ++sp;
+                if (t < 1.0f) {
+                    Bounce b = reflect_ray(d, f.normal, f.point);
+                    o = b.origin;
+                    d = b.direction;
+                    state = 0;
+                } else {
+                    state = 2;
+                }
+            }
+        }
     }
 }
 
-// ---------------------------------------------------------------------------
-// The kernel.
-// ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
