@@ -29,6 +29,7 @@ def timeit(d, w, h, flags, spp=32):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(); d.render(out.data_ptr(), w, h, p, st); e1.record(); torch.cuda.synchronize()
     stt = pt.host.read_stats()
+    timeit.lane_use = stt.rays / (64.0 * stt.wave_iters) if stt.wave_iters else 0.0
     return e0.elapsed_time(e1), stt.rays, out.cpu().numpy()
 
 def main():

@@ -7,6 +7,20 @@ import path_tracer_c_amd as pt
 from tools.bvh_scaling import timeit
 
 
+def timeit_b(d, bounces):
+    """as timeit, with a chosen bounce limit"""
+    out = torch.zeros((540, 960, 3), dtype=torch.uint8, device='cuda')
+    p = pt.make_params(spp=32, max_bounces=bounces, seed=1)
+    st = torch.cuda.current_stream().cuda_stream
+    d.render(out.data_ptr(), 960, 540, p, st); torch.cuda.synchronize()
+    pt.host.reset_stats()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(); d.render(out.data_ptr(), 960, 540, p, st); e1.record(); torch.cuda.synchronize()
+    stt = pt.host.read_stats()
+    timeit.lane_use = stt.rays / (64.0 * stt.wave_iters) if stt.wave_iters else 0.0
+    return e0.elapsed_time(e1), stt.rays, None
+
+
 def scene(n, branching, seed=1):
     rng = np.random.default_rng(seed)
     s = pt.HostScene()
@@ -25,9 +39,14 @@ def scene(n, branching, seed=1):
     return s
 
 
-for n in (8, 100, 1000):
+def main():
+  for n in (8, 100, 1000):
     for branching in (False, True):
-        with scene(n, branching) as s, pt.DeviceScene(s) as d:
-            ms, rays, _ = timeit(d, 960, 540, 0, spp=32)
+      with scene(n, branching) as s, pt.DeviceScene(s) as d:
+            ms, rays, _ = timeit(d, 960, 540, 0, spp=32) if len(sys.argv) < 2 else timeit_b(d, int(sys.argv[1]))
             print(f"n={n:5d} {'branching' if branching else 'paths    '}: {ms:8.2f} ms  {rays/ms/1e6:7.3f} Gray/s  "
-                  f"{rays/(960*540*32):6.2f} rays/sample  schedule {d.schedule}, scan {d.scan}", flush=True)
+                  f"{rays/(960*540*32):6.2f} rays/sample  lane use {timeit.lane_use:.3f}  schedule {d.schedule}, scan {d.scan}", flush=True)
+
+
+if __name__ == '__main__':
+    main()
