@@ -436,18 +436,36 @@ __device__ void run_tree(const SceneRecords &rec, const LaunchArgs &a, const Scr
                     continue;
                 }
                 Frame &f = frames[sp - 1];
-                if (!f.awaiting_transmit) {
-                    f.refl = ret;
-                    state = 2;
-                    continue;
-                }
-                // transmitted_Li arrived: finish this level
                 const F4 m0 = rec.mat[2 * f.material + 0];
                 const F4 m1 = rec.mat[2 * f.material + 1];
-                V3 li = lerp(f.refl, ret, m1.w);
-                ret = xyz(m1) + li * xyz(m0);
-                --sp; // state stays 1: return to the parent
-            } else { // state == 2
+                if (f.awaiting_transmit) {
+                    // transmitted_Li arrived: finish this level
+                    V3 li = lerp(f.refl, ret, m1.w);
+                    ret = xyz(m1) + li * xyz(m0);
+                    --sp; // state stays 1: return to the parent
+                    continue;
+                }
+                // reflected_Li arrived: on to the transmission branch, with the
+                // frame already in hand (one visit of the frame, not two)
+                f.refl = ret;
+                const float t = m1.w;
+                bool has_child = false;
+                if (t > 0.0f) {
+                    Bounce b = refract_ray(f.d_in, f.normal, f.point);
+                    has_child = b.has_child;
+                    if (has_child) {
+                        f.awaiting_transmit = 1;
+                        o = b.origin;
+                        d = b.direction;
+                        state = 0;
+                    }
+                }
+                if (!has_child) {
+                    V3 li = lerp(f.refl, splat(0.0f), t);
+                    ret = xyz(m1) + li * xyz(m0);
+                    --sp; // state stays 1
+                }
+            } else { // state == 2: a hit on a material with t >= 1 (no reflection child)
                 Frame &f = frames[sp - 1];
                 const F4 m0 = rec.mat[2 * f.material + 0];
                 const F4 m1 = rec.mat[2 * f.material + 1];
