@@ -415,7 +415,12 @@ __device__ void run_tree(const SceneRecords &rec, const LaunchArgs &a, const Scr
     //        2 = top frame must now evaluate its transmission branch
     //        3 = all samples done
     int state = spp != 0u ? 0 : 3;
+#ifdef PT_STAMPS
+    unsigned long long t_book = 0, t_trace = 0;
+    PT_STAMP(tree_begin);
+#endif
     for (;;) {
+        PT_STAMP(bk0);
         // ---- bookkeeping until a trace is due ----------------------------------
         while (state == 1 || state == 2 || (state == 0 && (uint32_t)sp > a.max_bounces)) {
             if (state == 0) { // the call is beyond the bounce limit: sky, no trace
@@ -489,6 +494,8 @@ __device__ void run_tree(const SceneRecords &rec, const LaunchArgs &a, const Scr
                 }
             }
         }
+        PT_STAMP(bk1);
+        PT_STAMP_ADD(t_book, bk1, bk0);
         if (!__any(state == 0))
             break; // every lane of the wave has finished its samples
         // ---- trace + shade for the lanes that stand before a call -----------------
@@ -522,7 +529,17 @@ __device__ void run_tree(const SceneRecords &rec, const LaunchArgs &a, const Scr
                 }
             }
         }
+        PT_STAMP(tr1);
+        PT_STAMP_ADD(t_trace, tr1, bk1);
     }
+#ifdef PT_STAMPS
+    PT_STAMP(tree_end);
+    if ((threadIdx.x & 63u) == 0u) {
+        atomicAdd(&g_stamps[5], t_book);
+        atomicAdd(&g_stamps[6], t_trace);
+        atomicAdd(&g_stamps[7], tree_end - tree_begin);
+    }
+#endif
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
