@@ -10,11 +10,11 @@ from tools.sweep_settle import run
 lib = pt.lib()
 fn = lib.ptgpu_debug_stamps
 fn.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-out = (C.c_ulonglong * 4)()
+out = (C.c_ulonglong * 8)()
 for name, kw in (('c2', {}), ('c0', {}), ('c1', dict(w=1920, h=1080, spp=64))):
     fn(out, 1)
     run(name, flags=0x80, reps=1, **kw)
     fn(out, 0)
-    scan, shade, settle, total = [float(x) for x in out]
+    scan, shade, settle, total = [float(x) for x in out][:4]
     print(f"{name}: scan {scan/total:.3f} shade {shade/total:.3f} settle {settle/total:.3f} "
           f"other {1-(scan+shade+settle)/total:.3f}")
