@@ -146,6 +146,24 @@ def read_profiled_traffic(workload):
         return None
 
 
+def bvh_work_roofline(workload, rays_per_launch, kernel_seconds):
+    """For a hierarchy scan the arithmetic actually asked of the device per ray
+    (measured averages of a counting build, profiles/bvh_work.json) against the
+    FP32 vector roof: the utilisation figure `achieved`/`frac` cannot give there."""
+    p = ROOT / "profiles" / "bvh_work.json"
+    try:
+        w = json.loads(p.read_text())[workload]
+    except Exception:
+        return {}
+    flop = (w["inner_node_steps_per_ray"] * w["flop_per_inner_step"] +
+            w["objects_screened_per_ray"] * w["flop_per_screen"] +
+            w["exact_tests_per_ray"] * w["flop_per_exact_sphere_test"] + w["flop_per_shade"])
+    achieved = rays_per_launch * flop / kernel_seconds / 1e12
+    return {"bvh_work": {"flop_per_ray": flop, "achieved": achieved, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
+                         "note": "per-ray averages measured with tools/bvh_profile.py (profiles/bvh_work.json)"}}
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -327,6 +345,7 @@ def main():
                 "note": "FP32 vector ALU roof (SURVEY.md 8(d)): no MFMA on this path and HBM "
                         "is not binding; peak = FP32 vector figure of "
                         "MI355X_MICROARCH.md (256 CUs x 4 SIMD-32 x 2 FLOP x 2.4 GHz)",
+                **(bvh_work_roofline(args.workload, rays_per_launch, k_s) if bvh else {}),
                 **({"equivalent": "rays are priced at the reference's linear scan (src/ray.c:12-65: "
                                   "every object tested); the hierarchy skips most of that arithmetic, "
                                   "so `achieved`/`frac` here measure the speed-up over the reference's "
