@@ -72,7 +72,7 @@ extern "C" {
                                          (8 samples per candidate form) and
                                          remembered; smaller renders go by
                                          object count: plain < 32 <= screened
-                                         < 192 <= BVH */
+                                         < 96 <= BVH */
 
 #define PTGPU_FLAG_PIXEL_OWNER 0x80u   /* scheduling only: one work-item owns a
                                          pixel for all its samples (one launch
@@ -91,7 +91,7 @@ extern "C" {
 
 #define PTGPU_FLAG_SCAN_BVH 0x400u     /* scheduling only: walk a bounding-volume
                                          hierarchy (built at upload for >= 64
-                                         objects; default for >= 192) instead
+                                         objects; default for >= 96) instead
                                          of scanning every object.  Candidates
                                          still get the reference's exact tests
                                          and accept rule: same image */

@@ -62,7 +62,7 @@ int fail_hip(hipError_t e, const char *where) {
 constexpr int kMaxDevices = 64;
 constexpr size_t kLdsBudget = 160u * 1024u; // one workgroup may own it all
 constexpr uint32_t kBvhMinObjects = 64;      // a hierarchy is built from here up
-constexpr uint32_t kBvhAutoObjects = 192;    // and used by default from here up
+constexpr uint32_t kBvhAutoObjects = 96;    // and used by default from here up
                                              // (measured: slower than the screened
                                              // linear scan at 250 objects, 1.2x
                                              // faster at 1000, 5.9x at 16000)
