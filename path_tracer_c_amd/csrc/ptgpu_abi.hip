@@ -185,10 +185,12 @@ struct ptgpu_scene {
     // -1 not measured, else 0 plain / 1 screened / 2 BVH.
     mutable std::atomic<int> scan_choice{-1};
     mutable std::atomic<int> last_mode{-1}; // schedule the latest render really used
-    // Do nearly all paths run to the bounce limit (closed scene)?  -1 not
-    // measured, 0 no, 1 yes: then a sample-synchronous wave wastes nothing, and
-    // the pixel-owner kernel may put several lanes on a pixel freely.
-    mutable std::atomic<int> full_depth{-1};
+    // Rays per sample measured by the pilots, in thousandths (-1: not
+    // measured).  Against the bounce limit it says how much a
+    // sample-synchronous wave would waste: nothing when nearly all paths run to
+    // the limit (closed scene), and then the pixel-owner kernel may put several
+    // lanes on a pixel freely.
+    mutable std::atomic<int> path_rays_milli{-1};
     uint64_t content_hash = 0; // of the uploaded records: key of the choice memo
     uint64_t serial = 0;       // unique per upload (never reused): identifies cached tables
 };
@@ -197,7 +199,7 @@ namespace {
 // Choices survive the handle: a caller that uploads the same scene again (the
 // one-shot ptgpu_render_frame does, every frame) finds them by content.
 struct Choice {
-    int queue_mode, scan_choice, full_depth;
+    int queue_mode, scan_choice, path_rays_milli;
 };
 std::mutex g_choice_mutex;
 std::map<uint64_t, Choice> g_choices;
@@ -224,7 +226,7 @@ void remember_choice(const ptgpu_scene *s) {
     std::lock_guard<std::mutex> guard(g_choice_mutex);
     if (g_choices.size() > 4096)
         g_choices.clear();
-    const Choice c{s->queue_mode.load(), s->scan_choice.load(), s->full_depth.load()};
+    const Choice c{s->queue_mode.load(), s->scan_choice.load(), s->path_rays_milli.load()};
     g_choices[s->content_hash] = c;
     g_choices[shape_key(s->desc)] = c;
 }
@@ -479,7 +481,7 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
         if (known != g_choices.end()) {
             h->queue_mode.store(known->second.queue_mode);
             h->scan_choice.store(known->second.scan_choice);
-            h->full_depth.store(known->second.full_depth);
+            h->path_rays_milli.store(known->second.path_rays_milli);
             if (h->scan_choice.load() == 2 && h->desc.bvh_nodes == nullptr)
                 h->scan_choice.store(-1); // inherited by shape, but no hierarchy here
         }
@@ -890,7 +892,18 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
             a.lanes_per_pixel = p->lanes_per_pixel;
         } else if (scratch_for_current_device(&probe) == PTGPU_OK && probe->max_waves > 0) {
             const double fill = (double)((npix + 63u) / 64u) / (double)probe->max_waves;
-            const double want = s->full_depth.load() == 1 ? 24.0 : 1.0;
+            // average path length over the longest possible one = the lane use
+            // of a sample-synchronous wave, roughly.  Near 1 (closed scene):
+            // ~24 rounds of waves.  From 0.4 (open scene, short bounce limit:
+            // the reference's own scene at its 4 bounces is 0.44): ~16 rounds,
+            // where the finer granularity still beats the idle lane-passes
+            // (1280x800: 0.65 -> 0.56 ms with 4 lanes; 1080p 1.04 -> 0.99 with
+            // 2).  Below that (the same scene at 8 bounces: 0.25) or unknown:
+            // only wave slots that would stay empty.
+            const int milli = s->path_rays_milli.load();
+            const double length_ratio =
+                milli < 0 ? 0.0 : std::min(1.0, 1e-3 * milli / ((double)a.max_bounces + 1.0));
+            const double want = length_ratio >= 0.93 ? 24.0 : length_ratio >= 0.4 ? 16.0 : 1.0;
             uint32_t k = 1u;
             while (fill * (2u * k) <= want * 1.34 && k < 16u && 2u * k <= total_spp)
                 k *= 2u;
@@ -1158,7 +1171,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
             s->scan_choice.store((int)cand[best]);
         const Tally &t = tally[best];
         const double rays_per_sample = t.samples > 0 ? t.rays / t.samples : 1.0;
-        s->full_depth.store(rays_per_sample >= 0.93 * ((double)a.max_bounces + 1.0) ? 1 : 0);
+        s->path_rays_milli.store((int)std::min(1e6, rays_per_sample * 1e3 + 0.5));
         if (a.screened == 2u) {
             mode = kSampleQueue; // resumable walks exist in queue form only
         } else {
