@@ -943,6 +943,41 @@ def test_statistical_parity_with_libc_random(gpu, oracle):
             assert abs(g[..., ch].astype(np.float64).mean() - a[..., ch].astype(np.float64).mean()) <= 0.25
 
 
+def test_host_threads_render_concurrently(gpu, oracle):
+    """Four host threads call ptgpu_render_frame at once (ctypes releases the
+    GIL): different scenes, sizes, schedules.  The library's shared state --
+    scratch buffers, the kept row buffer (one thread gets it, the others
+    allocate their own), choice memo, statistics -- must not mix frames up."""
+    import threading
+    jobs = [(0, 96, 60, dict(spp=6, max_bounces=4, seed=1)),
+            (2, 80, 45, dict(spp=5, max_bounces=8, seed=2, flags=0x100)),
+            (5, 64, 36, dict(spp=4, max_bounces=6, seed=3)),
+            (1, 72, 72, dict(spp=8, max_bounces=4, seed=4, lanes_per_pixel=4))]
+    scenes = [gpu.HostScene(cfg) for cfg, *_ in jobs]
+    refs = [oracle.render_rows(s, w, h, **{k: v for k, v in kw.items() if k in ("spp", "max_bounces", "seed")})[0]
+            for s, (_, w, h, kw) in zip(scenes, jobs)]
+    errors = []
+
+    def worker(i):
+        try:
+            _, w, h, kw = jobs[i]
+            for _ in range(6):
+                got = gpu.render_frame(scenes[i], w, h, **kw)
+                if not np.array_equal(got, refs[i]):
+                    errors.append(f"job {i}: frame differs")
+        except Exception as exc:                          # pragma: no cover
+            errors.append(f"job {i}: {exc!r}")
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for s in scenes:
+        s.close()
+    assert not errors, errors
+
+
 # ---- the legacy call sequence (threadpool + render_task) -----------------------------------
 def test_threadpool_render_task_frame(gpu, oracle, monkeypatch):
     monkeypatch.setenv("PTGPU_SPP", "8")
