@@ -16,7 +16,8 @@
 //   pt_resolve_kernel float4 accumulator -> RGB8
 //   pt_trace_kernel   batched trace_ray
 //
-// Common building blocks:
+// Common building blocks (pt_shade.h = one recursion level
+// for a lane, pt_owner.h = the pixel-owner loops, pt_trace.h = the scans):
 //   * the scene records are scanned with wave-uniform scalar loads (default)
 //     or from a per-workgroup LDS copy; three scan forms (plain, screened,
 //     BVH) in pt_trace.h;
@@ -38,509 +39,13 @@
 //
 // No MFMA: there is no dense contraction anywhere on this path.
 #include "pt_launch.h"
+#include "pt_owner.h"
+#include "pt_shade.h"
 #include "pt_trace.h"
 #include "pt_vec.h"
 #include "ptgpu_rng.h"
 
 namespace pt {
-
-// Refraction constants of src/renderer.c:58-63, with the reference's types:
-//   float refractive_index = dot < 0 ? 1.5 : 1 / 1.5;     (double -> float)
-//   eta = 1.0 / refractive_index                          (double -> float)
-__device__ constexpr float kIorEnter = (float)1.5;
-__device__ constexpr float kIorLeave = (float)(1 / 1.5);
-__device__ constexpr float kEtaEnter = (float)(1.0 / (double)kIorEnter);
-__device__ constexpr float kEtaLeave = (float)(1.0 / (double)kIorLeave);
-__device__ constexpr float kRayOffset = (float)0.001; // src/renderer.c:49,66
-
-// rand_unit_sphere (src/renderer.c:11-19): normalise a point of the cube
-// [-1,1)^3; three draws in x, y, z order.
-__device__ __forceinline__ V3 rand_unit_sphere(uint32_t &state) {
-    state = ptgpu_xorshift32(state);
-    float rx = ptgpu_u32_to_unit(state);
-    state = ptgpu_xorshift32(state);
-    float ry = ptgpu_u32_to_unit(state);
-    state = ptgpu_xorshift32(state);
-    float rz = ptgpu_u32_to_unit(state);
-    V3 cube = V3{rx, ry, rz} * 2.0f - splat(1.0f);
-    return normalize(cube);
-}
-
-// What one surface interaction decides (src/renderer.c:34-70), given the
-// perturbed normal: the next ray, or that the path has no child at this
-// level (total internal reflection / NaN transparency).
-struct Bounce {
-    V3 origin, direction;
-    bool has_child;
-};
-
-__device__ __forceinline__ Bounce reflect_ray(V3 d, V3 n, V3 point) {
-    Bounce b;
-    b.direction = normalize(reflect(d, n));
-    b.origin = point + b.direction * kRayOffset;
-    b.has_child = true;
-    return b;
-}
-
-__device__ __forceinline__ Bounce refract_ray(V3 d, V3 n, V3 point) {
-    Bounce b;
-    float facing = dot(d, n);
-    float eta = facing < 0.0f ? kEtaEnter : kEtaLeave;
-    V3 rn = facing < 0.0f ? n : -n;
-    V3 bent;
-    b.has_child = refract(d, rn, eta, bent);
-    b.direction = normalize(bent);
-    b.origin = point + b.direction * kRayOffset;
-    return b;
-}
-
-// One level of the unwind: Le + lerp(reflected, transmitted, t) * albedo
-// (src/renderer.c:72-73) where exactly one of the two children is `child`
-// and the other is the zero vector.
-__device__ __forceinline__ V3 shade_level(const F4 m0, const F4 m1, V3 child) {
-    const float t = m1.w;
-    const bool via_reflection = t < 1.0f;
-    V3 refl = via_reflection ? child : splat(0.0f);
-    V3 trans = via_reflection ? splat(0.0f) : child;
-    V3 li = lerp(refl, trans, t);
-    return xyz(m1) + li * xyz(m0);
-}
-
-// ---------------------------------------------------------------------------
-// Non-branching paths: every material has transparency <= 0 or >= 1.
-//
-// Wave-level schedule.  Each pass of the loop has two stages:
-//   trace+shade  lanes that own a live ray scan the scene and shade the hit,
-//                which either yields the next ray or ends the path (the lane
-//                then PARKS with the value its deepest call returns);
-//   settle       when the ballot says every lane is parked, or at least
-//                `settle_lanes` of them are, all parked lanes together unwind
-//                their recursion, add the clamped sample and regenerate their
-//                next sample's primary ray.
-// settle_lanes = 1 is plain per-lane path regeneration; 64 is a sample-
-// synchronous wave.  The settle stage is the divergent, scene-independent part
-// of a pass (9 dependent LDS-gather levels at 8 bounces); batching it trades a
-// few idle lane-passes for running it with many lanes instead of one or two.
-// The host picks settle_lanes from the scene size (a pass over 1000 objects
-// dwarfs a settle; a pass over 8 does not).  The image does not depend on it.
-// ---------------------------------------------------------------------------
-
-// Diagnostic build only (make EXTRA_HIPFLAGS=-DPT_STAMPS): wave-level cycle
-// shares of the scene scan, the shading and the settle stage, summed into
-// three device words that no kernel reads and no output depends on
-// (tools/stamps.py prints them).  The shipped library contains no stamp.
-#ifdef PT_STAMPS
-#define PT_STAMP(var)                                                          \
-    unsigned long long var;                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                         \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");  \
-    __builtin_amdgcn_sched_barrier(0)
-#define PT_STAMP_ADD(field, later, earlier) (field) += (later) - (earlier)
-__device__ unsigned long long g_stamps[8];
-#else
-#define PT_STAMP(var)
-#define PT_STAMP_ADD(field, later, earlier)
-#endif
-
-// State of one lane's path.
-struct PathState {
-#ifdef PT_STAMPS
-    unsigned long long t_scan = 0, t_shade = 0, t_settle = 0, t_total = 0;
-#endif
-    V3 o, d;        // ray to trace next
-    V3 r;           // value returned by the deepest call, once parked
-    uint32_t depth; // hits recorded on the bounce stack so far
-    uint32_t rng;
-    bool live;      // owns a ray to trace
-    bool parked;    // path ended, waiting for the settle stage
-};
-
-// kScan: 0 plain linear scan, 1 screened linear scan, 2 BVH scan.
-template <int kScan>
-__device__ __forceinline__ Hit scan_scene(const SceneRecords &rec, V3 o, V3 d,
-                                          const ScreenQueue queue) {
-    if (kScan == 2)
-        return closest_hit_bvh(rec, o, d, queue);
-    if (kScan == 1)
-        return closest_hit_screened(rec, o, d, queue);
-    return closest_hit(rec, o, d);
-}
-
-// One recursion level of incident_light for a live lane: scan the scene, then
-// either end the path (miss, depth limit, total internal reflection) or
-// produce the next ray (src/renderer.c:24-70).
-// `known` (wave-uniform): the closest hit of p's ray is already in `h_known`.
-template <int kScan>
-__device__ __forceinline__ void
-advance_path(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
-             uint32_t stack_stride, const ScreenQueue queue, V3 sky,
-             PathState &p, bool known = false, Hit h_known = Hit{-1.0f, -1}) {
-    PT_STAMP(stamp0);
-    const Hit h = known ? h_known : scan_scene<kScan>(rec, p.o, p.d, queue);
-    PT_STAMP(stamp1);
-    PT_STAMP_ADD(p.t_scan, stamp1, stamp0);
-    if (h.distance < 0.0f) { // miss: this level returns the sky colour
-        p.r = sky;
-        p.live = false;
-    } else {
-        const Surface sf = surface_at(rec, p.o, p.d, h);
-        stack[p.depth * stack_stride] = (uint16_t)sf.material;
-        ++p.depth;
-        const F4 m0 = rec.mat[2 * sf.material + 0];
-        const float transparency = rec.mat[2 * sf.material + 1].w;
-
-        V3 deviation = rand_unit_sphere(p.rng) * m0.w; // roughness * 0.5
-        V3 n = normalize(sf.normal + deviation);
-
-        Bounce b;
-        if (transparency < 1.0f) {
-            b = reflect_ray(p.d, n, sf.point);
-        } else if (transparency > 0.0f) {
-            b = refract_ray(p.d, n, sf.point);
-        } else { // NaN transparency: neither branch is taken
-            b.has_child = false;
-            b.origin = p.o;
-            b.direction = p.d;
-        }
-        p.o = b.origin;
-        p.d = b.direction;
-        p.r = splat(0.0f);
-        p.live = b.has_child;
-        if (p.live && p.depth > a.max_bounces) {
-            // the child call has bounces > MAX_BOUNCES: sky, no trace
-            p.r = sky;
-            p.live = false;
-        }
-    }
-    p.parked = !p.live;
-    PT_STAMP(stamp2);
-    PT_STAMP_ADD(p.t_shade, stamp2, stamp1);
-}
-
-// The unwind of a parked lane: re-apply Le + lerp(refl, trans, t) * albedo
-// from the deepest recorded level up; returns the clamped sample
-// (src/renderer.c:72-73, 88).
-__device__ __forceinline__ V3 unwind_path(const SceneRecords &rec,
-                                          const uint16_t *stack,
-                                          uint32_t stack_stride,
-                                          const PathState &p) {
-    V3 r = p.r;
-    for (uint32_t k = p.depth; k-- > 0;) {
-        const uint32_t m = stack[k * stack_stride];
-        r = shade_level(rec.mat[2 * m + 0], rec.mat[2 * m + 1], r);
-    }
-    return clamp01(r);
-}
-
-// Wave-uniform decision of the settle stage (see run_paths).
-__device__ __forceinline__ bool settle_now(bool live, bool parked,
-                                           uint32_t settle_lanes) {
-    const unsigned long long parked_mask = __ballot(parked);
-    const unsigned long long live_mask = __ballot(live);
-    return parked_mask != 0ull &&
-           (live_mask == 0ull || (uint32_t)__popcll(parked_mask) >= settle_lanes);
-}
-
-template <int kScan>
-__device__ __forceinline__ void
-run_paths(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
-          uint32_t stack_stride, const ScreenQueue queue, V3 d0, uint32_t pixel,
-          uint32_t spp, V3 sky, V3 &sum, uint32_t &rays, uint32_t &scans,
-          uint32_t &iters) {
-    uint32_t s = 0;
-    PathState p;
-    p.o = splat(0.0f);
-    p.d = d0;
-    p.r = splat(0.0f);
-    p.depth = 0;
-    p.rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset);
-    p.live = s < spp;
-    p.parked = false;
-
-    // Every sample of a pixel starts with the same un-jittered primary ray
-    // (src/renderer.c:96-100 computes x, y once per pixel), so its closest hit
-    // is the same: scan for it once.  The stored hit is used only on passes
-    // where every live lane of the wave is at a path's first segment -- a
-    // wave-uniform test, true at the start of nearly every sample when the
-    // wave's paths have equal lengths (closed scenes) -- otherwise the scan
-    // runs anyway for the other lanes and sharing would save nothing.
-    Hit h_primary = Hit{-1.0f, -1};
-    if (a.share_primary && p.live) {
-        h_primary = scan_scene<kScan>(rec, p.o, p.d, queue);
-        ++scans;
-    }
-
-    PT_STAMP(begin);
-    while (__any(p.live || p.parked)) {
-        ++iters;
-        const bool all_at_start = a.share_primary && !__any(p.live && p.depth != 0u);
-        if (p.live) {
-            ++rays;
-            if (!all_at_start)
-                ++scans;
-            advance_path<kScan>(rec, a, stack, stack_stride, queue, sky, p,
-                                all_at_start, h_primary);
-        }
-        PT_STAMP(settle0);
-        if (settle_now(p.live, p.parked, a.settle_lanes)) {
-            if (p.parked) {
-                sum = sum + unwind_path(rec, stack, stack_stride, p);
-                ++s;
-                p.depth = 0;
-                p.o = splat(0.0f);
-                p.d = d0;
-                p.rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset + s);
-                p.parked = false;
-                p.live = s < spp;
-            }
-        }
-        PT_STAMP(settle1);
-        PT_STAMP_ADD(p.t_settle, settle1, settle0);
-    }
-#ifdef PT_STAMPS
-    PT_STAMP(end);
-    if ((threadIdx.x & 63u) == 0u) {
-        atomicAdd(&g_stamps[0], p.t_scan);
-        atomicAdd(&g_stamps[1], p.t_shade);
-        atomicAdd(&g_stamps[2], p.t_settle);
-        atomicAdd(&g_stamps[3], end - begin);
-    }
-#endif
-}
-
-// ---------------------------------------------------------------------------
-// The same, with k = 2, 4, ... lanes per pixel (consecutive lanes of a wave).
-//
-// A row set that is too small to fill the device with one lane per pixel (a
-// shard of a frame split over many GPUs, a small image) gets k lanes per
-// pixel: in round r lane q of a pixel traces sample r*k + q.  The wave is
-// sample-synchronous here: when every lane has parked, all unwind, and the
-// pixel's first lane adds the k clamped samples IN SAMPLE ORDER, fetching its
-// partners' values with cross-lane reads -- so the sum is the very same
-// sequence of binary32 additions one lane would have made, and the image is
-// unchanged.  No HBM traffic, k times the waves.
-// ---------------------------------------------------------------------------
-template <int kScan>
-__device__ __forceinline__ void
-run_paths_split(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
-                uint32_t stack_stride, const ScreenQueue queue, V3 d0,
-                uint32_t pixel, uint32_t spp, uint32_t k, uint32_t q, V3 sky,
-                V3 &sum, uint32_t &rays, uint32_t &scans, uint32_t &iters,
-                uint32_t &samples_done) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t group = lane - q; // first lane of this pixel's group
-    const uint32_t rounds = (a.spp + k - 1u) / k;
-    PathState p;
-    p.r = splat(0.0f);
-    p.live = p.parked = false;
-
-    Hit h_primary = Hit{-1.0f, -1};
-    if (a.share_primary && spp != 0u) {
-        h_primary = scan_scene<kScan>(rec, splat(0.0f), d0, queue);
-        ++scans;
-    }
-
-    for (uint32_t round = 0; round < rounds; ++round) { // wave-uniform
-        const uint32_t s = round * k + q;
-        p.o = splat(0.0f);
-        p.d = d0;
-        p.depth = 0;
-        p.rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset + s);
-        p.live = s < spp;
-        p.parked = false;
-        const bool mine = p.live; // this lane traces a sample in this round
-
-        while (__any(p.live)) {
-            ++iters;
-            const bool all_at_start = a.share_primary && !__any(p.live && p.depth != 0u);
-            if (p.live) {
-                ++rays;
-                if (!all_at_start)
-                    ++scans;
-                advance_path<kScan>(rec, a, stack, stack_stride, queue, sky, p,
-                                    all_at_start, h_primary);
-            }
-        }
-        V3 sample = splat(0.0f);
-        if (mine) {
-            sample = unwind_path(rec, stack, stack_stride, p);
-            ++samples_done;
-        }
-        // the pixel's first lane adds samples round*k .. round*k + k-1, in order
-        for (uint32_t i = 0; i < k; ++i) {
-            const V3 other = V3{__shfl(sample.x, (int)(group + i), 64),
-                                __shfl(sample.y, (int)(group + i), 64),
-                                __shfl(sample.z, (int)(group + i), 64)};
-            if (round * k + i < spp)
-                sum = sum + other;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Branching paths: explicit depth-first evaluation of the recursion tree.
-// ---------------------------------------------------------------------------
-constexpr int kTreeFrames = 16; // PTGPU_MAX_BOUNCES_TREE + 2
-
-struct Frame {
-    V3 d_in;   // direction of the ray that hit this surface
-    V3 normal; // perturbed normal
-    V3 point;
-    V3 refl;   // reflected_Li once known
-    uint32_t material;
-    uint32_t awaiting_transmit; // 0: child in flight is the reflection
-};
-
-template <int kScan>
-__device__ void run_tree(const SceneRecords &rec, const LaunchArgs &a, const ScreenQueue queue,
-                         V3 d0, uint32_t pixel, uint32_t spp, V3 sky, V3 &sum,
-                         uint32_t &rays, uint32_t &iters) {
-    // Per lane: the recursion of incident_light as an explicit stack of frames,
-    // one sample after the other.  A pass of the outer loop has two parts:
-    //   bookkeeping  the lane returns values up its stack and picks the next
-    //                child to evaluate, until it stands before a call that
-    //                needs a ray traced (or has finished its last sample) --
-    //                cheap, lane by lane;
-    //   trace+shade  every lane that has such a call scans the scene and opens
-    //                the frame -- the expensive part, run with all of them at
-    //                once instead of whenever a lane happened to get there.
-    Frame frames[kTreeFrames];
-    uint32_t s = 0;
-    uint32_t rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset);
-    int sp = 0; // frames in use; a call at recursion depth k has sp == k
-    V3 o = splat(0.0f), d = d0;
-    V3 ret = splat(0.0f);
-    // state: 0 = enter a call with (o, d, bounces = sp)
-    //        1 = a call returned `ret` to the frame on top
-    //        2 = top frame must now evaluate its transmission branch
-    //        3 = all samples done
-    int state = spp != 0u ? 0 : 3;
-#ifdef PT_STAMPS
-    unsigned long long t_book = 0, t_trace = 0;
-    PT_STAMP(tree_begin);
-#endif
-    for (;;) {
-        PT_STAMP(bk0);
-        // ---- bookkeeping until a trace is due ----------------------------------
-        while (state == 1 || state == 2 || (state == 0 && (uint32_t)sp > a.max_bounces)) {
-            if (state == 0) { // the call is beyond the bounce limit: sky, no trace
-                ret = sky;
-                state = 1;
-            } else if (state == 1) {
-                if (sp == 0) { // the root call returned: the sample is complete
-                    sum = sum + clamp01(ret);
-                    ++s;
-                    if (s < spp) {
-                        rng = ptgpu_rng_seed(a.seed, pixel, a.sample_offset + s);
-                        o = splat(0.0f);
-                        d = d0;
-                        state = 0;
-                    } else {
-                        state = 3;
-                    }
-                    continue;
-                }
-                Frame &f = frames[sp - 1];
-                const F4 m0 = rec.mat[2 * f.material + 0];
-                const F4 m1 = rec.mat[2 * f.material + 1];
-                if (f.awaiting_transmit) {
-                    // transmitted_Li arrived: finish this level
-                    V3 li = lerp(f.refl, ret, m1.w);
-                    ret = xyz(m1) + li * xyz(m0);
-                    --sp; // state stays 1: return to the parent
-                    continue;
-                }
-                // reflected_Li arrived: on to the transmission branch, with the
-                // frame already in hand (one visit of the frame, not two)
-                f.refl = ret;
-                const float t = m1.w;
-                bool has_child = false;
-                if (t > 0.0f) {
-                    Bounce b = refract_ray(f.d_in, f.normal, f.point);
-                    has_child = b.has_child;
-                    if (has_child) {
-                        f.awaiting_transmit = 1;
-                        o = b.origin;
-                        d = b.direction;
-                        state = 0;
-                    }
-                }
-                if (!has_child) {
-                    V3 li = lerp(f.refl, splat(0.0f), t);
-                    ret = xyz(m1) + li * xyz(m0);
-                    --sp; // state stays 1
-                }
-            } else { // state == 2: a hit on a material with t >= 1 (no reflection child)
-                Frame &f = frames[sp - 1];
-                const F4 m0 = rec.mat[2 * f.material + 0];
-                const F4 m1 = rec.mat[2 * f.material + 1];
-                const float t = m1.w;
-                bool has_child = false;
-                if (t > 0.0f) {
-                    Bounce b = refract_ray(f.d_in, f.normal, f.point);
-                    has_child = b.has_child;
-                    if (has_child) {
-                        f.awaiting_transmit = 1;
-                        o = b.origin;
-                        d = b.direction;
-                        state = 0;
-                    }
-                }
-                if (!has_child) {
-                    V3 li = lerp(f.refl, splat(0.0f), t);
-                    ret = xyz(m1) + li * xyz(m0);
-                    --sp;
-                    state = 1;
-                }
-            }
-        }
-        PT_STAMP(bk1);
-        PT_STAMP_ADD(t_book, bk1, bk0);
-        if (!__any(state == 0))
-            break; // every lane of the wave has finished its samples
-        // ---- trace + shade for the lanes that stand before a call -----------------
-        ++iters;
-        if (state == 0) {
-            ++rays;
-            const Hit h = scan_scene<kScan>(rec, o, d, queue);
-            if (h.distance < 0.0f) {
-                ret = sky;
-                state = 1;
-            } else {
-                const Surface sf = surface_at(rec, o, d, h);
-                const F4 m0 = rec.mat[2 * sf.material + 0];
-                const float t = rec.mat[2 * sf.material + 1].w;
-                V3 deviation = rand_unit_sphere(rng) * m0.w;
-                Frame &f = frames[sp];
-                f.d_in = d;
-                f.normal = normalize(sf.normal + deviation);
-                f.point = sf.point;
-                f.refl = splat(0.0f);
-                f.material = sf.material;
-                f.awaiting_transmit = 0;
-                ++sp;
-                if (t < 1.0f) {
-                    Bounce b = reflect_ray(d, f.normal, f.point);
-                    o = b.origin;
-                    d = b.direction;
-                    state = 0;
-                } else {
-                    state = 2;
-                }
-            }
-        }
-        PT_STAMP(tr1);
-        PT_STAMP_ADD(t_trace, tr1, bk1);
-    }
-#ifdef PT_STAMPS
-    PT_STAMP(tree_end);
-    if ((threadIdx.x & 63u) == 0u) {
-        atomicAdd(&g_stamps[5], t_book);
-        atomicAdd(&g_stamps[6], t_trace);
-        atomicAdd(&g_stamps[7], tree_end - tree_begin);
-    }
-#endif
-}
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll

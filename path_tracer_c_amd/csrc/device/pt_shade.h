@@ -1,0 +1,219 @@
+// pt_shade.h -- one recursion level of incident_light (src/renderer.c:21-74)
+// for one lane, and what a path carries from level to level.
+//
+// incident_light's recursion is evaluated as a forward walk that records one
+// 16-bit material index per bounce in an LDS stack (advance_path), and an
+// unwind that re-applies `Le + lerp(refl, trans, t) * albedo` from the deepest
+// level up (unwind_path) -- the reference's own evaluation order, so results
+// are bit-equal to a sequential evaluation, which a throughput-product
+// formulation is not.  Per-lane xorshift32 in a register, re-seeded per
+// (pixel, sample) (include/ptgpu_rng.h), three draws per hit like
+// rand_unit_sphere (src/renderer.c:11-19).
+#pragma once
+
+#include "pt_layout.h"
+#include "pt_trace.h"
+#include "pt_vec.h"
+#include "ptgpu_rng.h"
+
+namespace pt {
+
+
+// Refraction constants of src/renderer.c:58-63, with the reference's types:
+//   float refractive_index = dot < 0 ? 1.5 : 1 / 1.5;     (double -> float)
+//   eta = 1.0 / refractive_index                          (double -> float)
+__device__ constexpr float kIorEnter = (float)1.5;
+__device__ constexpr float kIorLeave = (float)(1 / 1.5);
+__device__ constexpr float kEtaEnter = (float)(1.0 / (double)kIorEnter);
+__device__ constexpr float kEtaLeave = (float)(1.0 / (double)kIorLeave);
+__device__ constexpr float kRayOffset = (float)0.001; // src/renderer.c:49,66
+
+// rand_unit_sphere (src/renderer.c:11-19): normalise a point of the cube
+// [-1,1)^3; three draws in x, y, z order.
+__device__ __forceinline__ V3 rand_unit_sphere(uint32_t &state) {
+    state = ptgpu_xorshift32(state);
+    float rx = ptgpu_u32_to_unit(state);
+    state = ptgpu_xorshift32(state);
+    float ry = ptgpu_u32_to_unit(state);
+    state = ptgpu_xorshift32(state);
+    float rz = ptgpu_u32_to_unit(state);
+    V3 cube = V3{rx, ry, rz} * 2.0f - splat(1.0f);
+    return normalize(cube);
+}
+
+// What one surface interaction decides (src/renderer.c:34-70), given the
+// perturbed normal: the next ray, or that the path has no child at this
+// level (total internal reflection / NaN transparency).
+struct Bounce {
+    V3 origin, direction;
+    bool has_child;
+};
+
+__device__ __forceinline__ Bounce reflect_ray(V3 d, V3 n, V3 point) {
+    Bounce b;
+    b.direction = normalize(reflect(d, n));
+    b.origin = point + b.direction * kRayOffset;
+    b.has_child = true;
+    return b;
+}
+
+__device__ __forceinline__ Bounce refract_ray(V3 d, V3 n, V3 point) {
+    Bounce b;
+    float facing = dot(d, n);
+    float eta = facing < 0.0f ? kEtaEnter : kEtaLeave;
+    V3 rn = facing < 0.0f ? n : -n;
+    V3 bent;
+    b.has_child = refract(d, rn, eta, bent);
+    b.direction = normalize(bent);
+    b.origin = point + b.direction * kRayOffset;
+    return b;
+}
+
+// One level of the unwind: Le + lerp(reflected, transmitted, t) * albedo
+// (src/renderer.c:72-73) where exactly one of the two children is `child`
+// and the other is the zero vector.
+__device__ __forceinline__ V3 shade_level(const F4 m0, const F4 m1, V3 child) {
+    const float t = m1.w;
+    const bool via_reflection = t < 1.0f;
+    V3 refl = via_reflection ? child : splat(0.0f);
+    V3 trans = via_reflection ? splat(0.0f) : child;
+    V3 li = lerp(refl, trans, t);
+    return xyz(m1) + li * xyz(m0);
+}
+
+// ---------------------------------------------------------------------------
+// Non-branching paths: every material has transparency <= 0 or >= 1.
+//
+// Wave-level schedule.  Each pass of the loop has two stages:
+//   trace+shade  lanes that own a live ray scan the scene and shade the hit,
+//                which either yields the next ray or ends the path (the lane
+//                then PARKS with the value its deepest call returns);
+//   settle       when the ballot says every lane is parked, or at least
+//                `settle_lanes` of them are, all parked lanes together unwind
+//                their recursion, add the clamped sample and regenerate their
+//                next sample's primary ray.
+// settle_lanes = 1 is plain per-lane path regeneration; 64 is a sample-
+// synchronous wave.  The settle stage is the divergent, scene-independent part
+// of a pass (9 dependent LDS-gather levels at 8 bounces); batching it trades a
+// few idle lane-passes for running it with many lanes instead of one or two.
+// The host picks settle_lanes from the scene size (a pass over 1000 objects
+// dwarfs a settle; a pass over 8 does not).  The image does not depend on it.
+// ---------------------------------------------------------------------------
+
+// Diagnostic build only (make EXTRA_HIPFLAGS=-DPT_STAMPS): wave-level cycle
+// shares of the scene scan, the shading and the settle stage, summed into
+// three device words that no kernel reads and no output depends on
+// (tools/stamps.py prints them).  The shipped library contains no stamp.
+#ifdef PT_STAMPS
+#define PT_STAMP(var)                                                          \
+    unsigned long long var;                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");  \
+    __builtin_amdgcn_sched_barrier(0)
+#define PT_STAMP_ADD(field, later, earlier) (field) += (later) - (earlier)
+__device__ unsigned long long g_stamps[8];
+#else
+#define PT_STAMP(var)
+#define PT_STAMP_ADD(field, later, earlier)
+#endif
+
+// State of one lane's path.
+struct PathState {
+#ifdef PT_STAMPS
+    unsigned long long t_scan = 0, t_shade = 0, t_settle = 0, t_total = 0;
+#endif
+    V3 o, d;        // ray to trace next
+    V3 r;           // value returned by the deepest call, once parked
+    uint32_t depth; // hits recorded on the bounce stack so far
+    uint32_t rng;
+    bool live;      // owns a ray to trace
+    bool parked;    // path ended, waiting for the settle stage
+};
+
+// kScan: 0 plain linear scan, 1 screened linear scan, 2 BVH scan.
+template <int kScan>
+__device__ __forceinline__ Hit scan_scene(const SceneRecords &rec, V3 o, V3 d,
+                                          const ScreenQueue queue) {
+    if (kScan == 2)
+        return closest_hit_bvh(rec, o, d, queue);
+    if (kScan == 1)
+        return closest_hit_screened(rec, o, d, queue);
+    return closest_hit(rec, o, d);
+}
+
+// One recursion level of incident_light for a live lane: scan the scene, then
+// either end the path (miss, depth limit, total internal reflection) or
+// produce the next ray (src/renderer.c:24-70).
+// `known` (wave-uniform): the closest hit of p's ray is already in `h_known`.
+template <int kScan>
+__device__ __forceinline__ void
+advance_path(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
+             uint32_t stack_stride, const ScreenQueue queue, V3 sky,
+             PathState &p, bool known = false, Hit h_known = Hit{-1.0f, -1}) {
+    PT_STAMP(stamp0);
+    const Hit h = known ? h_known : scan_scene<kScan>(rec, p.o, p.d, queue);
+    PT_STAMP(stamp1);
+    PT_STAMP_ADD(p.t_scan, stamp1, stamp0);
+    if (h.distance < 0.0f) { // miss: this level returns the sky colour
+        p.r = sky;
+        p.live = false;
+    } else {
+        const Surface sf = surface_at(rec, p.o, p.d, h);
+        stack[p.depth * stack_stride] = (uint16_t)sf.material;
+        ++p.depth;
+        const F4 m0 = rec.mat[2 * sf.material + 0];
+        const float transparency = rec.mat[2 * sf.material + 1].w;
+
+        V3 deviation = rand_unit_sphere(p.rng) * m0.w; // roughness * 0.5
+        V3 n = normalize(sf.normal + deviation);
+
+        Bounce b;
+        if (transparency < 1.0f) {
+            b = reflect_ray(p.d, n, sf.point);
+        } else if (transparency > 0.0f) {
+            b = refract_ray(p.d, n, sf.point);
+        } else { // NaN transparency: neither branch is taken
+            b.has_child = false;
+            b.origin = p.o;
+            b.direction = p.d;
+        }
+        p.o = b.origin;
+        p.d = b.direction;
+        p.r = splat(0.0f);
+        p.live = b.has_child;
+        if (p.live && p.depth > a.max_bounces) {
+            // the child call has bounces > MAX_BOUNCES: sky, no trace
+            p.r = sky;
+            p.live = false;
+        }
+    }
+    p.parked = !p.live;
+    PT_STAMP(stamp2);
+    PT_STAMP_ADD(p.t_shade, stamp2, stamp1);
+}
+
+// The unwind of a parked lane: re-apply Le + lerp(refl, trans, t) * albedo
+// from the deepest recorded level up; returns the clamped sample
+// (src/renderer.c:72-73, 88).
+__device__ __forceinline__ V3 unwind_path(const SceneRecords &rec,
+                                          const uint16_t *stack,
+                                          uint32_t stack_stride,
+                                          const PathState &p) {
+    V3 r = p.r;
+    for (uint32_t k = p.depth; k-- > 0;) {
+        const uint32_t m = stack[k * stack_stride];
+        r = shade_level(rec.mat[2 * m + 0], rec.mat[2 * m + 1], r);
+    }
+    return clamp01(r);
+}
+
+// Wave-uniform decision of the settle stage (see run_paths).
+__device__ __forceinline__ bool settle_now(bool live, bool parked,
+                                           uint32_t settle_lanes) {
+    const unsigned long long parked_mask = __ballot(parked);
+    const unsigned long long live_mask = __ballot(live);
+    return parked_mask != 0ull &&
+           (live_mask == 0ull || (uint32_t)__popcll(parked_mask) >= settle_lanes);
+}
+
+} // namespace pt
