@@ -405,6 +405,24 @@ def test_lanes_per_pixel_store_paths(gpu, oracle, torch_cuda, k, block):
         assert compact.shape[0] == sh.num_rows and np.array_equal(compact, ref[rows])
 
 
+@pytest.mark.parametrize("k", [1, 4, 8])
+@pytest.mark.parametrize("shift", [1, 2, 3])
+def test_frame_buffers_need_no_alignment(gpu, oracle, torch_cuda, k, shift):
+    """The RGB8 destination may start at any byte: the dword store paths step
+    aside for byte stores, nothing is written before or after the frame."""
+    torch = torch_cuda
+    w, h = 64, 33
+    with gpu.HostScene(2) as s, gpu.DeviceScene(s) as d:
+        ref, _ = oracle.render_rows(s, w, h, spp=4, max_bounces=5, seed=3)
+        buf = torch.full((3 * w * h + 8,), 77, dtype=torch.uint8, device="cuda")
+        p = gpu.make_params(spp=4, max_bounces=5, seed=3, flags=0x80, lanes_per_pixel=k)
+        d.render(buf.data_ptr() + shift, w, h, p, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy()
+    assert np.array_equal(got[shift:shift + 3 * w * h].reshape(h, w, 3), ref)
+    assert (got[:shift] == 77).all() and (got[shift + 3 * w * h:] == 77).all()
+
+
 def test_lanes_per_pixel_progressive_and_stats(gpu):
     """Accumulator passes with several lanes per pixel equal the one-lane
     passes bit for bit, and the counters still count every sample once."""
