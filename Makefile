@@ -21,8 +21,14 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-s
             -Wall -Wno-unused-function -Iinclude -I$(CSRC)
 CFLAGS   := -std=gnu2x -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude
 
+# The tolerance mode (PTGPU_FLAG_FAST_MATH): the same device sources compiled a
+# second time into namespace pt_fast with contraction on and the approximate
+# sqrt / rcp / rsq instructions as they come (csrc/device/pt_vec.h).
+FASTFLAGS := $(filter-out -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt,$(HIPFLAGS)) \
+             -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -DPT_FAST_MATH -DPT_NS=pt_fast $(EXTRA_FASTFLAGS)
+
 HOST_OBJS := $(BUILD)/scene.o $(BUILD)/vector.o $(BUILD)/bitmap.o $(BUILD)/scenes.o
-HIP_OBJS  := $(BUILD)/pt_kernels.o $(BUILD)/ptgpu_abi.o
+HIP_OBJS  := $(BUILD)/pt_kernels.o $(BUILD)/pt_kernels_fast.o $(BUILD)/ptgpu_abi.o
 DEV_HDRS  := $(wildcard $(CSRC)/device/*.h) $(wildcard $(CSRC)/*.hpp) $(wildcard include/*.h)
 
 all: $(LIBDIR)/libptgpu.so oracle bin/ptrender
@@ -35,6 +41,9 @@ $(BUILD)/%.o: $(CSRC)/host/%.c include/path_tracer_api.h include/ptgpu.h | $(BUI
 
 $(BUILD)/pt_kernels.o: $(CSRC)/device/pt_kernels.hip $(DEV_HDRS) | $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(BUILD)/pt_kernels_fast.o: $(CSRC)/device/pt_kernels.hip $(DEV_HDRS) | $(BUILD)
+	$(HIPCC) $(FASTFLAGS) -c $< -o $@
 
 $(BUILD)/ptgpu_abi.o: $(CSRC)/ptgpu_abi.hip $(DEV_HDRS) | $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -66,9 +75,10 @@ CLANG     := /opt/rocm/lib/llvm/bin/clang
 asan-driver: | $(BUILD) bin
 	$(HIPCC) $(filter-out -O3,$(HIPFLAGS)) -O1 -g $(ASAN_HOST) -c $(CSRC)/ptgpu_abi.hip -o $(BUILD)/asan_abi.o
 	$(HIPCC) $(filter-out -O3,$(HIPFLAGS)) -O1 -g -c $(CSRC)/device/pt_kernels.hip -o $(BUILD)/asan_kernels.o
+	$(HIPCC) $(filter-out -O3,$(FASTFLAGS)) -O1 -g -c $(CSRC)/device/pt_kernels.hip -o $(BUILD)/asan_kernels_fast.o
 	for f in scene vector bitmap scenes main; do \
 	  $(CLANG) -std=gnu2x -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -ffp-contract=off -Iinclude \
 	    -c $(CSRC)/host/$$f.c -o $(BUILD)/asan_$$f.o || exit 1; done
 	$(HIPCC) --offload-arch=$(ARCH) -fno-gpu-sanitize -fsanitize=address,undefined -o bin/ptrender_asan \
 	  $(BUILD)/asan_main.o $(BUILD)/asan_scene.o $(BUILD)/asan_vector.o $(BUILD)/asan_bitmap.o $(BUILD)/asan_scenes.o \
-	  $(BUILD)/asan_abi.o $(BUILD)/asan_kernels.o -lpthread -lm
+	  $(BUILD)/asan_abi.o $(BUILD)/asan_kernels.o $(BUILD)/asan_kernels_fast.o -lpthread -lm

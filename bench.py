@@ -346,16 +346,27 @@ def main():
                         "is not binding; peak = FP32 vector figure of "
                         "MI355X_MICROARCH.md (256 CUs x 4 SIMD-32 x 2 FLOP x 2.4 GHz)",
                 **(bvh_work_roofline(args.workload, rays_per_launch, k_s) if bvh else {}),
-                **({"equivalent": "rays are priced at the reference's linear scan (src/ray.c:12-65: "
-                                  "every object tested); the hierarchy skips most of that arithmetic, "
-                                  "so `achieved`/`frac` here measure the speed-up over the reference's "
-                                  "algorithm at the ALU roof, not ALU utilisation"} if bvh else {}),
                 "traffic": read_profiled_traffic(args.workload),
                 "hbm": {"algorithmic_bytes_per_launch": hbm_alg,
                         "achieved": hbm_alg / k_s / 1e9, "peak": PEAK_HBM_GBS,
                         "unit": "GB/s", "frac": hbm_alg / k_s / 1e9 / PEAK_HBM_GBS},
             },
         }
+        if bvh and "bvh_work" in line["roofline"]:
+            # A hierarchy scan does not execute the reference's linear scan, so
+            # pricing its rays at 17 FLOP x every object would report a
+            # "fraction" above 1.  The utilisation figure is the arithmetic the
+            # walk really asks for (measured per-ray averages); the linear-scan
+            # pricing is kept beside it as a speed-up, never as `frac`.
+            rf = line["roofline"]
+            work = rf.pop("bvh_work")
+            rf["linear_scan_equivalent"] = {
+                "flop_per_ray": rf["flop_per_ray"], "tflops": rf["achieved"],
+                "note": "rays priced at the reference's linear scan (src/ray.c:12-65: every "
+                        "object tested); ratio to the roof = speed-up over the reference's "
+                        "algorithm run at the ALU roof, not a utilisation"}
+            rf["achieved"], rf["frac"], rf["flop_per_ray"] = work["achieved"], work["frac"], work["flop_per_ray"]
+            rf["note"] += "; flop_per_ray = " + work["note"]
         assert st.scans == st.rays, "headline must scan the scene for every counted ray"
         if world == 1 and not progressive:
             # library default: primary-ray scan shared between a pixel's samples

@@ -105,6 +105,20 @@ extern "C" {
                                          as the reference does, instead of once
                                          per pixel (the ray is the same) */
 
+#define PTGPU_FLAG_FAST_MATH 0x1000u    /* NOT scheduling only -- the opt-in
+                                         tolerance mode.  The same kernels built
+                                         with fused multiply-adds, the hardware's
+                                         approximate sqrt / reciprocal / rsqrt
+                                         (1 ulp) and the 17-FLOP sphere
+                                         discriminant instead of the reference's
+                                         sequentially rounded arithmetic.  Same
+                                         algorithm, same random stream; the frame
+                                         agrees with the exact one to a stated
+                                         tolerance (>= 99.9 % of bytes within +-1,
+                                         RMSE <= 0.5 of an 8-bit level), not to
+                                         the bit.  Also accepted in the
+                                         scan_flags of the trace_rays calls */
+
 /* limits */
 #define PTGPU_MAX_BOUNCES_PATH 62 /* non-branching kernel (LDS material stack) */
 #define PTGPU_MAX_BOUNCES_TREE 14 /* branching kernel (per-lane frame stack) */

@@ -41,6 +41,7 @@ FLAG_NO_PRIMARY_SHARE = 0x200
 FLAG_SCAN_BVH = 0x400
 FLAG_SCAN_SCREENED = 0x20
 FLAG_WHOLE_WALKS = 0x800
+FLAG_FAST_MATH = 0x1000
 
 MAX_BOUNCES_PATH = 62
 MAX_BOUNCES_TREE = 14

@@ -45,7 +45,7 @@
 #include "pt_vec.h"
 #include "ptgpu_rng.h"
 
-namespace pt {
+namespace PT_NS {
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
@@ -179,7 +179,7 @@ __device__ __forceinline__ PixelSite pixel_site(const LaunchArgs &a, uint32_t j)
     const float aspect = fw / fh;
     const float x = (float)sx / fw * 2.0f - 1.0f;
     const float y = -((float)grow / fh * 2.0f - 1.0f);
-    ps.d0 = normalize(V3{x * a.tan_half_fov, y * a.tan_half_fov / aspect, 1.0f});
+    ps.d0 = normalize_dir(V3{x * a.tan_half_fov, y * a.tan_half_fov / aspect, 1.0f});
     return ps;
 }
 
@@ -1079,7 +1079,7 @@ hipError_t launch_sum(const LaunchArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-#ifdef PT_STAMPS
+#if defined(PT_STAMPS) && !defined(PT_FAST_MATH)
 extern "C" int ptgpu_debug_stamps(unsigned long long out[8], int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8) != hipSuccess)
         return -1;
@@ -1092,7 +1092,7 @@ extern "C" int ptgpu_debug_stamps(unsigned long long out[8], int reset) {
 }
 #endif
 
-#ifdef PT_BVH_PROFILE
+#if defined(PT_BVH_PROFILE) && !defined(PT_FAST_MATH)
 extern "C" int ptgpu_debug_bvh_profile(unsigned long long out[12], int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_profile), sizeof(unsigned long long) * 12) != hipSuccess)
         return -1;
@@ -1138,4 +1138,4 @@ hipError_t launch_trace(const SceneDesc &scene, const float *origins,
     return hipGetLastError();
 }
 
-} // namespace pt
+} // namespace PT_NS

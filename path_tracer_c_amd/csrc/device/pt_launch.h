@@ -18,23 +18,35 @@ struct DeviceRayHit {
 };
 static_assert(sizeof(DeviceRayHit) == 40, "must match ray_hit");
 
-// Dynamic LDS one workgroup of `block` work-items needs for this launch.
-size_t megakernel_lds_bytes(const LaunchArgs &a, uint32_t block, bool tree);
-
-hipError_t launch_megakernel(const LaunchArgs &a, uint32_t block, bool tree,
-                             hipStream_t stream);
-// Sample-queue mode: persistent waves pulling (pixel, sample) tasks, then the
-// ordered per-pixel sum.  `max_waves` = waves the device keeps resident.
-hipError_t launch_samplekernel(const LaunchArgs &a, uint32_t block,
-                               uint32_t max_waves, hipStream_t stream);
-hipError_t launch_sum(const LaunchArgs &a, hipStream_t stream);
-// Closest hit of each local pixel's primary ray (BVH scan): 8 bytes per pixel.
-hipError_t launch_primary(const LaunchArgs &a, float *primary_hits, hipStream_t stream);
-hipError_t launch_resolve(const float *accum, uint8_t *frame, uint64_t npixels,
-                          hipStream_t stream);
-// scan: 0 plain, 1 screened linear, 2 BVH (the scene must have a hierarchy)
-hipError_t launch_trace(const SceneDesc &scene, const float *origins,
-                        const float *directions, uint64_t n,
-                        DeviceRayHit *hits, int scan, hipStream_t stream);
-
 } // namespace pt
+
+// The launchers exist twice: `pt` = the bit-exact build of the device code,
+// `pt_fast` = the same sources compiled as the tolerance mode (pt_vec.h).
+#define PT_DECLARE_LAUNCHERS                                                                       \
+    /* Dynamic LDS one workgroup of `block` work-items needs for this launch. */                   \
+    size_t megakernel_lds_bytes(const pt::LaunchArgs &a, uint32_t block, bool tree);               \
+    hipError_t launch_megakernel(const pt::LaunchArgs &a, uint32_t block, bool tree,               \
+                                 hipStream_t stream);                                              \
+    /* Sample-queue mode: persistent waves pulling (pixel, sample) tasks, then the ordered         \
+     * per-pixel sum.  `max_waves` = waves the device keeps resident. */                           \
+    hipError_t launch_samplekernel(const pt::LaunchArgs &a, uint32_t block, uint32_t max_waves,    \
+                                   hipStream_t stream);                                            \
+    hipError_t launch_sum(const pt::LaunchArgs &a, hipStream_t stream);                            \
+    /* Closest hit of each local pixel's primary ray (BVH scan): 8 bytes per pixel. */             \
+    hipError_t launch_primary(const pt::LaunchArgs &a, float *primary_hits, hipStream_t stream);   \
+    hipError_t launch_resolve(const float *accum, uint8_t *frame, uint64_t npixels,                \
+                              hipStream_t stream);                                                 \
+    /* scan: 0 plain, 1 screened linear, 2 BVH (the scene must have a hierarchy) */                \
+    hipError_t launch_trace(const pt::SceneDesc &scene, const float *origins,                      \
+                            const float *directions, uint64_t n, pt::DeviceRayHit *hits, int scan, \
+                            hipStream_t stream);
+
+#ifndef PT_FAST_MATH // (hidden from the pt_fast build itself: its unqualified calls would find
+                     // these too, through the argument types' namespace)
+namespace pt {
+PT_DECLARE_LAUNCHERS
+}
+#endif
+namespace pt_fast {
+PT_DECLARE_LAUNCHERS
+}

@@ -8,7 +8,7 @@
 
 #include "pt_shade.h"
 
-namespace pt {
+namespace PT_NS {
 
 template <int kScan>
 __device__ __forceinline__ void
@@ -311,4 +311,4 @@ __device__ void run_tree(const SceneRecords &rec, const LaunchArgs &a, const Scr
 #endif
 }
 
-} // namespace pt
+} // namespace PT_NS

@@ -16,7 +16,7 @@
 #include "pt_vec.h"
 #include "ptgpu_rng.h"
 
-namespace pt {
+namespace PT_NS {
 
 
 // Refraction constants of src/renderer.c:58-63, with the reference's types:
@@ -51,7 +51,7 @@ struct Bounce {
 
 __device__ __forceinline__ Bounce reflect_ray(V3 d, V3 n, V3 point) {
     Bounce b;
-    b.direction = normalize(reflect(d, n));
+    b.direction = normalize_dir(reflect(d, n));
     b.origin = point + b.direction * kRayOffset;
     b.has_child = true;
     return b;
@@ -64,7 +64,7 @@ __device__ __forceinline__ Bounce refract_ray(V3 d, V3 n, V3 point) {
     V3 rn = facing < 0.0f ? n : -n;
     V3 bent;
     b.has_child = refract(d, rn, eta, bent);
-    b.direction = normalize(bent);
+    b.direction = normalize_dir(bent);
     b.origin = point + b.direction * kRayOffset;
     return b;
 }
@@ -216,4 +216,4 @@ __device__ __forceinline__ bool settle_now(bool live, bool parked,
            (live_mask == 0ull || (uint32_t)__popcll(parked_mask) >= settle_lanes);
 }
 
-} // namespace pt
+} // namespace PT_NS

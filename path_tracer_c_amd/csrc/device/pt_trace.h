@@ -17,7 +17,7 @@
 #include "pt_layout.h"
 #include "pt_vec.h"
 
-namespace pt {
+namespace PT_NS {
 
 // A view of the scene records, in LDS or in global memory.
 struct SceneRecords {
@@ -49,6 +49,30 @@ PT_HD bool is_triangle_record(const F4 &g) {
 // glms_ray_sphere for a unit direction; `r2` is radius*radius.
 // Returns false when there is no root or both roots are behind the origin.
 PT_HD bool ray_sphere(V3 o, V3 d, V3 c, float r2, float &t1, float &t2) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PT_FAST_SPHERE)
+    // tolerance mode: the 17-FLOP discriminant b^2 - (|dp|^2 - r^2) without the
+    // remedy term, fused; the roots still as q and c/q (no cancellation: a ray
+    // leaving a radius-1000 wall must not find that wall again), with
+    // v_sqrt_f32 / v_rcp_f32 as they come
+    // (|dp|^2 - r^2 decides on which side of the surface the origin lies, and a
+    // ray leaving a radius-1000 sphere by 0.001 sits within one or two of its
+    // rounding steps of zero: the reference's own self-intersection rule lives
+    // in the last bits of this value, so it is rounded exactly as the
+    // reference rounds it -- otherwise a few per cent of all paths through such
+    // a scene take a different, if equally valid, course)
+    const V3 dp = c - o;
+    const float b = dot(d, dp);
+    const float cc = dot_seq(dp, dp) - r2;
+    const float disc = __builtin_fmaf(b, b, -cc);
+    if (disc < 0.0f)
+        return false;
+    const float s = __builtin_amdgcn_sqrtf(disc);
+    const float q = (b >= 0.0f) ? (b + s) : (b - s);
+    const float other = cc * __builtin_amdgcn_rcpf(q);
+    t1 = __builtin_fminf(q, other);
+    t2 = __builtin_fmaxf(q, other);
+    return !(t2 < 0.0f);
+#else
     V3 dp = c - o;
     float ddp = dot(d, dp);
     float dpp = dot(dp, dp);
@@ -68,6 +92,7 @@ PT_HD bool ray_sphere(V3 o, V3 d, V3 c, float r2, float &t1, float &t2) {
     t1 = a;
     t2 = b;
     return !(a < 0.0f && b < 0.0f);
+#endif
 }
 
 // glms_ray_triangle (Moeller-Trumbore, eps 1e-6, two-sided) with the edges
@@ -708,4 +733,4 @@ PT_HD Surface surface_at(const SceneRecords &rec, V3 o, V3 d, Hit h) {
     return s;
 }
 
-} // namespace pt
+} // namespace PT_NS

@@ -22,7 +22,34 @@
 
 #define PT_HD __host__ __device__ __forceinline__
 
-namespace pt {
+// The device code is compiled twice (Makefile): as namespace `pt` under the
+// bit-exact contract described above, and -- with -DPT_FAST_MATH
+// -DPT_NS=pt_fast -ffp-contract=fast -- as namespace `pt_fast`, the opt-in
+// tolerance mode behind PTGPU_FLAG_FAST_MATH (include/ptgpu.h): fused
+// multiply-adds, v_sqrt_f32 / v_rcp_f32 / v_rsq_f32 without their correction
+// steps, the 17-FLOP discriminant.  Same algorithm, same random stream, same
+// launch plumbing; results agree with the exact build to the tolerance
+// tests/test_parity_gpu.py states, not to the bit.  The layout types
+// (pt_layout.h, pt_launch.h) live in `pt` for both.
+#ifndef PT_NS
+#define PT_NS pt
+#endif
+// (the two halves of the mode can be switched off one by one when looking for
+// the source of a difference: -DPT_EXACT_SPHERE, -DPT_EXACT_RECIP)
+#if defined(PT_FAST_MATH) && !defined(PT_EXACT_SPHERE)
+#define PT_FAST_SPHERE 1
+#endif
+#if defined(PT_FAST_MATH) && !defined(PT_EXACT_RECIP)
+#define PT_FAST_RECIP 1
+#endif
+#ifdef PT_FAST_MATH
+#include "pt_layout.h"
+namespace pt_fast {
+using namespace pt;
+}
+#endif
+
+namespace PT_NS {
 
 struct V3 {
     float x, y, z;
@@ -39,6 +66,18 @@ PT_HD V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
 
 // x*x' + y*y' + z*z', summed left to right (glms_vec3_dot).
 PT_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// The same sum with every product and sum rounded on its own, also in the
+// tolerance build, where -ffp-contract=fast lets the backend fuse any multiply
+// with any add (no pragma stops that; an empty asm the products pass through
+// does, at no instruction).
+PT_HD float dot_seq(V3 a, V3 b) {
+    float px = a.x * b.x, py = a.y * b.y, pz = a.z * b.z;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PT_FAST_MATH)
+    asm("" : "+v"(px), "+v"(py), "+v"(pz));
+#endif
+    return px + py + pz;
+}
 
 PT_HD V3 cross(V3 a, V3 b) {
     return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z,
@@ -76,26 +115,46 @@ __device__ __forceinline__ float rcp_core(float x) { // 2^-62 <= |x| <= 2^62
 #endif
 
 PT_HD float sqrt_rn(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PT_FAST_RECIP)
+    return __builtin_amdgcn_sqrtf(x); // v_sqrt_f32, 1 ulp
+#else
 #if defined(__HIP_DEVICE_COMPILE__)
     if (__builtin_expect(x >= 0x1.0p-96f, 1))
         return sqrt_core(x);
 #endif
     return sqrtf(x);
+#endif
 }
 
 PT_HD float rcp_rn(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PT_FAST_RECIP)
+    return __builtin_amdgcn_rcpf(x); // v_rcp_f32, 1 ulp
+#else
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t mag = f32_bits(x) & 0x7FFFFFFFu;
     if (__builtin_expect(mag - 0x20800000u <= 0x3E000000u, 1)) // [2^-62, 2^62]
         return rcp_core(x);
 #endif
     return 1.0f / x;
+#endif
 }
 
 // glms_vec3_normalize: zero vector below FLT_EPSILON, else a * (1/|a|).
 PT_HD V3 normalize(V3 a) {
     const float len2 = dot(a, a);
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PT_FAST_RECIP) && !defined(PT_EXACT_NORMALIZE)
+    // len < FLT_EPSILON <=> len2 < FLT_EPSILON^2 (up to rounding); v_rsq_f32
+    if (!(len2 >= FLT_EPSILON * FLT_EPSILON))
+        return (len2 != len2) ? splat(len2) : splat(0.0f);
+    // One Newton step on top of v_rsq_f32.  The instruction alone is good to
+    // 1 ulp but sits 0.085 ulp low on average (tools/rsq_bias.hip), and unit
+    // vectors that are all a hair short made configuration 5's paths 0.8 %
+    // longer and its image 0.15 of an 8-bit level darker than the exact
+    // build's (tools/fast_math_probe3.py); three more instructions remove it.
+    const float y = __builtin_amdgcn_rsqf(len2);
+    const float e = __builtin_fmaf(-(len2 * y), y, 1.0f);
+    return a * __builtin_fmaf(0.5f * y, e, y);
+#elif defined(__HIP_DEVICE_COMPILE__)
     // one range test covers both fast paths: 2^-96 <= len2 <= 2^124 puts
     // len in [2^-48, 2^62]
     if (__builtin_expect(f32_bits(len2) - 0x0F800000u <= 0x6E000000u, 1)) {
@@ -110,6 +169,36 @@ PT_HD V3 normalize(V3 a) {
         return splat(0.0f);
     float inv = 1.0f / len;
     return a * inv;
+}
+
+// Normalisation of a RAY DIRECTION: the reference's chain -- correctly rounded
+// sqrt, correctly rounded reciprocal, three products -- in BOTH builds.
+// ray_sphere takes the direction for a unit vector, so a length error eps
+// misplaces a hit by eps * distance; rays that have leaked into a radius-1000
+// sphere (reflected below the surface; the reference lets them) travel chords
+// of up to 2000 units, where 1e-7 * 2000 = 2e-4 is of the order of the 0.001
+// origin offset and of that sphere's 6e-5 position rounding: whether such a
+// ray stays trapped inside until the bounce limit or escapes depends on the
+// SIGN of eps.  Measured on configuration 5 (tools/fast_math_probe3.py, 8
+// bounces): all reflected directions scaled by 1 -/+ 1e-7: 3.42 / 3.33 rays per
+// sample against 3.37, and the image 0.3 / 0.1 of an 8-bit level darker /
+// brighter.  v_rsq_f32 (+ a Newton step) is as accurate as this chain but
+// distributes eps differently, which made the tolerance build's paths 0.6 %
+// longer and its picture 0.12 levels darker; with this chain at the three
+// direction sites it is 0.01 % and 0.02 levels.  Normals keep the cheap form.
+PT_HD V3 normalize_dir(V3 a) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PT_FAST_RECIP)
+    const float len2 = dot_seq(a, a);
+    if (__builtin_expect(f32_bits(len2) - 0x0F800000u <= 0x6E000000u, 1)) {
+        const float len = sqrt_core(len2);
+        if (len < FLT_EPSILON)
+            return splat(0.0f);
+        return a * rcp_core(len);
+    }
+    return normalize(a);
+#else
+    return normalize(a);
+#endif
 }
 
 // glms_vec3_lerp: from + (to - from) * t, not clamped.
@@ -145,4 +234,4 @@ PT_HD bool refract(V3 v, V3 n, float eta, V3 &out) {
     return true;
 }
 
-} // namespace pt
+} // namespace PT_NS

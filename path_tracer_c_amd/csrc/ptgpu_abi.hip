@@ -680,6 +680,24 @@ int prepare_launch(const ptgpu_scene *s, size_t framew, size_t frameh,
     return PTGPU_OK;
 }
 
+// The two builds of the device code (csrc/device/pt_vec.h): bit-exact, and the
+// opt-in tolerance mode (PTGPU_FLAG_FAST_MATH).
+struct Launchers {
+    decltype(&pt::launch_megakernel) megakernel;
+    decltype(&pt::launch_samplekernel) samplekernel;
+    decltype(&pt::launch_sum) sum;
+    decltype(&pt::launch_primary) primary;
+    decltype(&pt::launch_trace) trace;
+};
+const Launchers kExactBuild{&pt::launch_megakernel, &pt::launch_samplekernel, &pt::launch_sum,
+                            &pt::launch_primary, &pt::launch_trace};
+const Launchers kFastBuild{&pt_fast::launch_megakernel, &pt_fast::launch_samplekernel,
+                           &pt_fast::launch_sum, &pt_fast::launch_primary,
+                           &pt_fast::launch_trace};
+const Launchers *launchers_for(uint32_t flags) {
+    return (flags & PTGPU_FLAG_FAST_MATH) ? &kFastBuild : &kExactBuild;
+}
+
 // launches are counted on the host (per device)
 std::atomic<unsigned long long> g_launches[kMaxDevices];
 
@@ -700,8 +718,9 @@ struct PrimaryView {
     uint64_t scene_serial = 0;
     uint32_t framew = 0, frameh = 0, row_begin = 0, num_rows = 0, tile_rows = 0, tile_stride = 0;
     uint32_t tan_half_fov_bits = 0;
+    uint32_t fast_math = 0; // which build of the device code computed the table
     bool operator==(const PrimaryView &o) const {
-        return scene_serial == o.scene_serial && framew == o.framew && frameh == o.frameh &&
+        return fast_math == o.fast_math && scene_serial == o.scene_serial && framew == o.framew && frameh == o.frameh &&
                row_begin == o.row_begin && num_rows == o.num_rows && tile_rows == o.tile_rows &&
                tile_stride == o.tile_stride && tan_half_fov_bits == o.tan_half_fov_bits;
     }
@@ -857,6 +876,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         return rc;
     const uint64_t npix = (uint64_t)a.num_rows * a.framew;
     const uint32_t total_spp = a.spp;
+    const Launchers &L = *launchers_for(p->flags);
     TimedCall timed(a.counters != nullptr, stream); // part of the statistics
 
     // ---- which schedule ------------------------------------------------------
@@ -945,7 +965,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         a.frame = d_frame;  // exactly one of the two is non-null
         a.accum = d_accum;
         a.accum_local = 0;
-        hipError_t e = pt::launch_megakernel(a, owner_block, tree, stream);
+        hipError_t e = L.megakernel(a, owner_block, tree, stream);
         if (e != hipSuccess)
             return fail_hip(e, "megakernel launch");
         count_launch();
@@ -1019,13 +1039,14 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
                 // the table of the previous pass)
                 const PrimaryView view{s->serial, a.framew, a.frameh, a.row_begin, a.num_rows,
                                        a.tile_rows, a.tile_stride,
-                                       __builtin_bit_cast(uint32_t, a.tan_half_fov)};
+                                       __builtin_bit_cast(uint32_t, a.tan_half_fov),
+                                       (p->flags & PTGPU_FLAG_FAST_MATH) ? 1u : 0u};
                 if (!(sc->primary_view == view) || sc->primary_bytes < (size_t)npix * 8u) {
                     sc->primary_view = PrimaryView{};
                     grc = grow(&sc->primary, &sc->primary_bytes, (size_t)npix * 8u);
                     if (grc != PTGPU_OK)
                         return grc;
-                    hipError_t pe = pt::launch_primary(a, sc->primary, stream);
+                    hipError_t pe = L.primary(a, sc->primary, stream);
                     if (pe != hipSuccess)
                         return fail_hip(pe, "primary-hit launch");
                     sc->primary_view = view;
@@ -1041,7 +1062,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
             q.reshade_lanes = kStreamReshadeLanes;
             q.shade_lanes = kStreamShadeLanes;
         }
-        hipError_t e = pt::launch_samplekernel(q, block, sc->max_waves, stream);
+        hipError_t e = L.samplekernel(q, block, sc->max_waves, stream);
         if (e != hipSuccess)
             return fail_hip(e, "sample kernel launch");
         count_launch();
@@ -1052,7 +1073,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         q.first_pass = accum_is_zero ? 1u : 0u;
         accum_is_zero = false;
         q.frame = (d_frame != nullptr && done_spp == total_spp) ? d_frame : nullptr;
-        e = pt::launch_sum(q, stream);
+        e = L.sum(q, stream);
         if (e != hipSuccess)
             return fail_hip(e, "sum kernel launch");
         return PTGPU_OK;
@@ -1130,7 +1151,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
                 q.screened = scan;
                 q.spp = count;
                 q.sample_offset = a.sample_offset + done_spp;
-                hipError_t e = pt::launch_megakernel(q, owner_block, false, stream);
+                hipError_t e = L.megakernel(q, owner_block, false, stream);
                 if (e != hipSuccess)
                     return fail_hip(e, "megakernel launch (pilot)");
                 count_launch();
@@ -1198,7 +1219,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
             pt::LaunchArgs q = a;
             q.spp = total_spp - done_spp;
             q.sample_offset = a.sample_offset + done_spp;
-            hipError_t e = pt::launch_megakernel(q, owner_block, tree, stream);
+            hipError_t e = L.megakernel(q, owner_block, tree, stream);
             if (e != hipSuccess)
                 return fail_hip(e, "megakernel launch (accumulate)");
             count_launch();
@@ -1209,7 +1230,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
             q.spp = 0;
             q.first_pass = 0;
             q.frame = d_frame;
-            hipError_t e = pt::launch_sum(q, stream);
+            hipError_t e = L.sum(q, stream);
             if (e != hipSuccess)
                 return fail_hip(e, "resolve launch");
             timed.add_bytes(19ull * npix);
@@ -1532,7 +1553,8 @@ int ptgpu_trace_rays_scan(const scene *host_scene, const float *origins,
         }
         scan = 2;
     }
-    if (e == hipSuccess) e = pt::launch_trace(s->desc, d_o, d_d, n, d_h, scan, nullptr);
+    if (e == hipSuccess)
+        e = launchers_for(scan_flags)->trace(s->desc, d_o, d_d, n, d_h, scan, nullptr);
     if (e == hipSuccess)
         e = hipMemcpy(hits, d_h, sizeof(pt::DeviceRayHit) * n, hipMemcpyDeviceToHost);
     if (d_o) (void)hipFree(d_o);
@@ -1563,9 +1585,9 @@ int ptgpu_trace_rays_device(const ptgpu_scene *s, const float *d_origins,
             return fail(PTGPU_ERR_INVALID, "scene has no hierarchy (fewer than 64 objects)");
         scan = 2;
     }
-    hipError_t e = pt::launch_trace(s->desc, d_origins, d_directions, n,
-                                    reinterpret_cast<pt::DeviceRayHit *>(d_hits), scan,
-                                    (hipStream_t)hip_stream);
+    hipError_t e = launchers_for(scan_flags)->trace(s->desc, d_origins, d_directions, n,
+                                                   reinterpret_cast<pt::DeviceRayHit *>(d_hits),
+                                                   scan, (hipStream_t)hip_stream);
     if (e != hipSuccess)
         return fail_hip(e, "trace_rays_device");
     return PTGPU_OK;

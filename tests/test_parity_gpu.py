@@ -1169,3 +1169,216 @@ def test_full_size_config5_rows_against_the_oracle(gpu, torch_cuda, oracle):
         ref, _ = oracle.render_rows(s, w, h, 400, 401, spp=16, **kw)
     assert np.array_equal(lds, glob)                    # global scan == LDS tile
     assert np.array_equal(lds[400], ref[400])
+
+
+# ---- BASELINE.json configs[2..4] at FULL size (round 2) ---------------------------------
+def _oracle_rows(oracle, scene, w, h, rows, threads=3, **kw):
+    """The oracle on a few single rows, one thread per row (the stream is a
+    function of the global pixel index, so rows can be checked in isolation)."""
+    out = {}
+    for y in rows:
+        ref, _ = oracle.render_rows(scene, w, h, y, y + 1, **kw)
+        out[y] = ref[y]
+    return out
+
+
+def test_full_size_config3_progressive_4096_spp_against_the_oracle(gpu, torch_cuda, oracle):
+    """BASELINE configs[2]: config 2's scene, 4096 spp accumulated progressively
+    on one GPU -- 16 passes of 256 spp into a float4 accumulator, then the
+    resolve.  The oracle accumulates all 4096 samples of two rows in one go;
+    the float sums must be bit-equal (same additions in the same order) and so
+    must the resolved bytes."""
+    torch = torch_cuda
+    c = gpu.CONFIGS[3]
+    w, h, spp = c["width"], c["height"], c["spp"]
+    assert (w, h, spp) == (1920, 1080, 4096)
+    stream = torch.cuda.current_stream().cuda_stream
+    kw = dict(max_bounces=c["max_bounces"], seed=c["seed"])
+    gpu.host.reset_stats()
+    with gpu.HostScene(c["scene"]) as s, gpu.DeviceScene(s) as d:
+        acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        for k in range(16):
+            d.accumulate(acc.data_ptr(), w, h,
+                         gpu.make_params(spp=256, sample_offset=256 * k, **kw), stream)
+        out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+        gpu.host.resolve(acc.data_ptr(), out.data_ptr(), w * h, stream)
+        torch.cuda.synchronize()
+        st = gpu.host.read_stats()
+        assert st.samples == w * h * spp
+        got_acc, got = acc.cpu().numpy(), out.cpu().numpy()
+        for y in (17, 702):
+            ref = np.zeros((h, w, 4), dtype=f32)
+            oracle.accumulate_rows(s, ref, w, h, y, y + 1, spp=spp, **kw)
+            assert np.array_equal(bits(got_acc[y]), bits(ref[y])), f"accumulator row {y}"
+            ref8, _ = oracle.render_rows(s, w, h, y, y + 1, spp=spp, **kw)
+            assert np.array_equal(got[y], ref8[y]), f"frame row {y}"
+    assert (got_acc[..., 3] == spp).all()
+
+
+def test_full_size_config4_4k_1024_spp_against_the_oracle(gpu, torch_cuda, oracle):
+    """BASELINE configs[3] on ONE GPU: 3840x2160, 1024 spp, 8 bounces in one
+    launch; then the same frame as the 8-rank row-tile deal would produce it
+    (8-row tiles, tile t -> rank t mod 8, compact shards) for two of the eight
+    ranks -- the shard of a rank must equal its rows of the single launch."""
+    from path_tracer_c_amd import tiles
+    c = gpu.CONFIGS[4]
+    w, h = c["width"], c["height"]
+    assert (w, h, c["spp"]) == (3840, 2160, 1024)
+    kw = dict(spp=c["spp"], max_bounces=c["max_bounces"], seed=c["seed"])
+    gpu.host.reset_stats()
+    with gpu.HostScene(c["scene"]) as s, gpu.DeviceScene(s) as d:
+        frame = render_device(gpu, torch_cuda, d, w, h, **kw)
+        st = gpu.host.read_stats()
+        assert st.samples == w * h * c["spp"]
+        for y, row in _oracle_rows(oracle, s, w, h, (3, 1400), **kw).items():
+            assert np.array_equal(frame[y], row), f"row {y}"
+        for rank in (0, 5):
+            sh = tiles.shard_rows(h, 8, rank, 8)
+            part = render_device(gpu, torch_cuda, d, w, h, row_begin=sh.row_begin,
+                                 num_rows=sh.num_rows, tile_rows=sh.tile_rows,
+                                 tile_stride=sh.tile_stride,
+                                 flags=gpu._abi.FLAG_COMPACT_ROWS, **kw)
+            assert np.array_equal(part[: sh.num_rows], frame[sh.global_rows()]), f"rank {rank}"
+
+
+def test_full_size_config5_256_spp_against_the_oracle(gpu, torch_cuda, oracle):
+    """BASELINE configs[4] at its real 256 spp: 1001 spheres, 1920x1080, library
+    defaults (BVH scan, sample queue, resumable walks, primary hits shared).
+    One sky-heavy and one ground row against the oracle's linear scan."""
+    c = gpu.CONFIGS[5]
+    w, h = c["width"], c["height"]
+    assert (w, h, c["spp"]) == (1920, 1080, 256)
+    kw = dict(spp=c["spp"], max_bounces=c["max_bounces"], seed=c["seed"])
+    gpu.host.reset_stats()
+    with gpu.HostScene(c["scene"]) as s, gpu.DeviceScene(s) as d:
+        frame = render_device(gpu, torch_cuda, d, w, h, **kw)
+        st = gpu.host.read_stats()
+        assert st.samples == w * h * c["spp"]
+        assert d.scan == "bvh" and d.schedule == "sample-queue"
+        for y, row in _oracle_rows(oracle, s, w, h, (40, 830), **kw).items():
+            assert np.array_equal(frame[y], row), f"row {y}"
+
+
+@pytest.mark.parametrize("workload,scene,w,h,spp", [("c4", 2, 3840, 2160, 1024),
+                                                    ("c5", 5, 1920, 1080, 256),
+                                                    ("c3", 2, 1920, 1080, 4096)])
+def test_bench_lines_of_the_other_configs_parse(gpu, workload, scene, w, h, spp):
+    """`bench.py --workload c3|c4|c5` prints one JSON line with the contract's
+    keys, names the BASELINE configuration it ran and never reports a
+    roofline fraction above 1."""
+    import json
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--workload", workload,
+                          "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                         check=True, capture_output=True, text=True, timeout=900).stdout
+    line = json.loads(out.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 1 and line["unit"] == "Mray/s"
+    assert line["value"] > 1000.0                     # north_star's floor: 1 Gray/s
+    wl = line["config"]["workload"]
+    assert f"config {workload[1]}" in wl and f"{w}x{h}" in wl and f"{spp} spp" in wl
+    rf = line["roofline"]
+    assert 0.0 < rf["frac"] <= 1.0 and rf["achieved"] <= rf["peak"]
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+
+
+# ---- the opt-in tolerance mode (PTGPU_FLAG_FAST_MATH, round 2) -----------------------------
+def _fast_vs_exact(gpu, torch_cuda, scene, w, h, **kw):
+    A = gpu._abi
+    with gpu.HostScene(scene) as s, gpu.DeviceScene(s) as d:
+        exact = render_device(gpu, torch_cuda, d, w, h, flags=A.FLAG_NO_PRIMARY_SHARE, **kw)
+        fast = render_device(gpu, torch_cuda, d, w, h,
+                             flags=A.FLAG_NO_PRIMARY_SHARE | A.FLAG_FAST_MATH, **kw)
+        other = render_device(gpu, torch_cuda, d, w, h, flags=A.FLAG_NO_PRIMARY_SHARE,
+                              **{**kw, "seed": kw["seed"] + 1})
+    return exact.astype(np.int32), fast.astype(np.int32), other.astype(np.int32)
+
+
+def _rmse(a, b):
+    return float(np.sqrt(np.mean((a - b).astype(np.float64) ** 2)))
+
+
+@pytest.mark.parametrize("name,scene,w,h,spp,b,seed", [
+    ("c2", 2, 1920, 1080, 256, 8, 1),       # BASELINE config 2 at full size
+    ("demo", 0, 1280, 800, 16, 4, 1),       # the reference's scene at its window size / settings
+    ("c1", 1, 256, 256, 16, 4, 12345),      # BASELINE config 1
+])
+def test_fast_math_frames_are_within_the_stated_tolerance(gpu, torch_cuda, name, scene, w, h, spp,
+                                                          b, seed):
+    """Tolerance of the FAST_MATH build against the exact GPU frame, same
+    stream: RMSE <= 0.5 of an 8-bit level and >= 99.9 % of the
+    bytes within +-1 -- at 16 spp, where ONE sample that takes another course
+    moves a byte by up to 255/16 levels, >= 99.5 % -- and no mean shift.  A
+    silhouette pixel may flip as a whole (the primary ray is not jittered,
+    src/renderer.c:96-100), so no bound on the largest single difference."""
+    exact, fast, _ = _fast_vs_exact(gpu, torch_cuda, scene, w, h, spp=spp, max_bounces=b, seed=seed)
+    diff = fast - exact
+    assert _rmse(fast, exact) <= 0.5
+    assert np.mean(np.abs(diff) <= 1) >= (0.999 if spp >= 64 else 0.995)
+    assert abs(diff.mean()) <= 0.02
+    assert (diff != 0).any()            # it IS another build, not the exact one again
+
+
+def test_fast_math_on_a_chaotic_scene_is_statistically_the_same_picture(gpu, torch_cuda):
+    """Configuration 5 (1000 small spheres: a bounce off a radius-0.3 sphere
+    multiplies a direction error by ~100) is chaotic: after three bounces a
+    last-bit difference is a different path, so a fifth of the bytes differ --
+    as they would between any two floating-point environments that do not
+    round identically (this is why the default build is bit-exact).  What a
+    tolerance build can be held to here is that its frame is another fair
+    sample of the same picture: closer to the exact frame than the exact
+    frame rendered with another seed is (measured: RMSE 1.96 levels against
+    3.45 between seeds), and without a brightness
+    shift (a length bias of 1e-7 in the ray directions alone would shift it by
+    0.3 levels: csrc/device/pt_vec.h, normalize_dir)."""
+    exact, fast, other = _fast_vs_exact(gpu, torch_cuda, 5, 1920, 1080, spp=256, max_bounces=8, seed=1)
+    noise = _rmse(other, exact)
+    assert _rmse(fast, exact) <= 0.75 * noise
+    assert abs((fast - exact).mean()) <= 0.1
+    assert np.mean(np.abs(fast - exact) <= 1) >= 0.95
+
+
+def test_fast_math_is_the_same_picture_whatever_the_schedule(gpu, torch_cuda):
+    """Inside the tolerance build the scheduling flags stay scheduling only:
+    plain / screened / BVH scan, pixel owner / sample queue, lanes per pixel
+    and progressive passes give the same bytes."""
+    A = gpu._abi
+    w, h = 240, 135
+    kw = dict(spp=16, max_bounces=8, seed=5)
+    with gpu.HostScene(5) as s, gpu.DeviceScene(s) as d:
+        ref = render_device(gpu, torch_cuda, d, w, h, flags=A.FLAG_FAST_MATH | A.FLAG_SCAN_PLAIN |
+                            A.FLAG_PIXEL_OWNER, **kw)
+        for flags in (A.FLAG_SCAN_SCREENED | A.FLAG_PIXEL_OWNER, A.FLAG_SCAN_BVH | A.FLAG_PIXEL_OWNER,
+                      A.FLAG_SCAN_BVH | A.FLAG_SAMPLE_QUEUE, A.FLAG_SCAN_BVH | A.FLAG_SAMPLE_QUEUE |
+                      A.FLAG_WHOLE_WALKS, A.FLAG_SCAN_PLAIN | A.FLAG_SAMPLE_QUEUE, A.FLAG_SCENE_LDS,
+                      A.FLAG_NO_PRIMARY_SHARE):
+            got = render_device(gpu, torch_cuda, d, w, h, flags=A.FLAG_FAST_MATH | flags, **kw)
+            assert np.array_equal(got, ref), hex(flags)
+        got = render_device(gpu, torch_cuda, d, w, h, flags=A.FLAG_FAST_MATH, lanes_per_pixel=4, **kw)
+        assert np.array_equal(got, ref)
+
+
+def test_fast_math_rays_agree_with_the_exact_hits(gpu):
+    """ptgpu_trace_rays_scan with FAST_MATH in scan_flags: same object, distance
+    within 1e-5 relative, for all but the grazing few."""
+    A = gpu._abi
+    rng = np.random.default_rng(23)
+    n = 200000
+    d = rng.normal(size=(n, 3)).astype(f32)
+    d[:, 2] = np.abs(d[:, 2]) + 0.2
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(f32)
+    o = np.zeros((n, 3), f32)
+    for cfg in (0, 2, 5):
+        with gpu.HostScene(cfg) as s:
+            e = gpu.trace_rays(s, o, d, 0)
+            f = gpu.trace_rays(s, o, d, A.FLAG_FAST_MATH)
+        same = (e[0] >= 0) == (f[0] >= 0)
+        assert same.mean() >= 0.9999
+        both = (e[0] >= 0) & (f[0] >= 0)
+        close = np.abs(e[0][both] - f[0][both]) <= 1e-5 * np.abs(e[0][both]) + 1e-6
+        assert close.mean() >= 0.9999
+        assert (e[3][both] == f[3][both]).mean() >= 0.9999
