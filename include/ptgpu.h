@@ -251,6 +251,45 @@ int ptgpu_render_frame_multi(const scene *host_scene, uint8_t *frame,
                              const ptgpu_params *p, const int *devices,
                              int n_devices, uint32_t tile_rows);
 
+/* -- one process, several GPUs, frame assembled IN HBM (RCCL over xGMI) ------- */
+/* The same row-tile deal as above, but the frame never leaves the devices:
+ * every device renders its tiles into a compact shard in its own HBM, ONE
+ * grouped ncclSend/ncclRecv (rccl.h:700,722) brings the shards of devices
+ * 1..n-1 to device 0 -- each peer over its own xGMI link -- and a small
+ * kernel on device 0 puts the rows in place.  A plain C host
+ * gets its frame in HBM on devices[0], ready for a resolve / encode / display
+ * step there.  librccl is loaded on first use (dlopen), so hosts that never
+ * call this pay nothing for it.
+ *
+ *   ptgpu_multi_create   communicators (ncclCommInitAll, rccl.h:236), one
+ *                        stream per device; `devices` are HIP ordinals, all
+ *                        different, n_devices >= 2 -- else PTGPU_ERR_LIMIT.
+ *                        flags = PTGPU_MULTI_PEER_COPY: no RCCL; shards travel
+ *                        by hipMemcpyPeerAsync instead, ordinals may repeat
+ *                        (a rehearsal of everything but the collective on a
+ *                        box with one GPU, and a fallback where librccl is
+ *                        missing)
+ *   ptgpu_multi_upload   replicates the scene on every device (<= 56 KB)
+ *   ptgpu_multi_render   one frame into `d_frame` (device memory of
+ *                        devices[0], full-frame addressing, RGB8); returns
+ *                        when the frame is complete.  `p` must not carry a
+ *                        tile deal of its own; tile_rows 0 = 8.  The frame is
+ *                        the single-device frame, bit for bit.
+ *   ptgpu_render_device_multi   create + upload + render + destroy in one call
+ */
+#define PTGPU_MULTI_PEER_COPY 0x1u
+typedef struct ptgpu_multi ptgpu_multi;
+int ptgpu_multi_create(const int *devices, int n_devices, uint32_t flags, ptgpu_multi **out);
+int ptgpu_multi_upload(ptgpu_multi *m, const scene *host_scene);
+int ptgpu_multi_render(ptgpu_multi *m, uint8_t *d_frame, size_t framew, size_t frameh,
+                       const ptgpu_params *p, uint32_t tile_rows);
+/* "rccl" or "peer-copy" */
+const char *ptgpu_multi_transport(const ptgpu_multi *m);
+void ptgpu_multi_destroy(ptgpu_multi *m);
+int ptgpu_render_device_multi(const scene *host_scene, uint8_t *d_frame_on_device0,
+                              size_t framew, size_t frameh, const ptgpu_params *p,
+                              const int *devices, int n_devices, uint32_t tile_rows);
+
 /* -- device memory helpers for hosts without a HIP binding (C, cgo, ctypes) -- */
 int ptgpu_device_alloc(size_t bytes, void **out); /* hipMalloc, zero-filled */
 int ptgpu_device_free(void *ptr);

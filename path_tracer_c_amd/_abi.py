@@ -42,6 +42,7 @@ FLAG_SCAN_BVH = 0x400
 FLAG_SCAN_SCREENED = 0x20
 FLAG_WHOLE_WALKS = 0x800
 FLAG_FAST_MATH = 0x1000
+MULTI_PEER_COPY = 0x1
 
 MAX_BOUNCES_PATH = 62
 MAX_BOUNCES_TREE = 14
@@ -209,6 +210,16 @@ SIGNATURES = {
     "ptgpu_render_frame_multi": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_size_t,
                                            C.c_size_t, C.POINTER(Params),
                                            C.POINTER(C.c_int), C.c_int, C.c_uint32]),
+    "ptgpu_multi_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_uint32,
+                                     C.POINTER(C.c_void_p)]),
+    "ptgpu_multi_upload": (C.c_int, [C.c_void_p, C.POINTER(Scene)]),
+    "ptgpu_multi_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                     C.POINTER(Params), C.c_uint32]),
+    "ptgpu_multi_transport": (C.c_char_p, [C.c_void_p]),
+    "ptgpu_multi_destroy": (None, [C.c_void_p]),
+    "ptgpu_render_device_multi": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_size_t,
+                                            C.c_size_t, C.POINTER(Params),
+                                            C.POINTER(C.c_int), C.c_int, C.c_uint32]),
     "ptgpu_device_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "ptgpu_device_free": (C.c_int, [C.c_void_p]),
     "ptgpu_device_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

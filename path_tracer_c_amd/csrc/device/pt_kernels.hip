@@ -1116,6 +1116,49 @@ hipError_t launch_resolve(const float *accum, uint8_t *frame, uint64_t npixels,
     return hipGetLastError();
 }
 
+#ifndef PT_FAST_MATH
+// One workgroup per frame row of the call's row set: copies the row from its
+// shard in the staging buffer (pt_launch.h, ScatterArgs).  16-byte moves when
+// source and destination allow, bytes otherwise.  HBM-bound: 3*W bytes read +
+// written per row.
+__global__ void __launch_bounds__(256) pt_scatter_kernel(const ScatterArgs s) {
+    const uint32_t i = blockIdx.x; // row of the set
+    if (i >= s.num_rows)
+        return;
+    const uint32_t tile = i / s.tile_rows;
+    const uint32_t shard = tile % s.shards;
+    const uint32_t local = (tile / s.shards) * s.tile_rows + (i - tile * s.tile_rows);
+    const uint8_t *src = s.stage + s.shard_offset[shard] + (uint64_t)local * s.row_bytes;
+    uint8_t *dst = s.frame + (uint64_t)(s.row_begin + i) * s.row_bytes;
+    const uintptr_t both = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst);
+    uint32_t done = 0;
+    if ((both & 15u) == 0u) {
+        const uint32_t n16 = s.row_bytes / 16u;
+        const uint4 *s16 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d16 = reinterpret_cast<uint4 *>(dst);
+        for (uint32_t k = threadIdx.x; k < n16; k += blockDim.x)
+            d16[k] = s16[k];
+        done = n16 * 16u;
+    } else if ((both & 3u) == 0u) {
+        const uint32_t n4 = s.row_bytes / 4u;
+        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src);
+        uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
+        for (uint32_t k = threadIdx.x; k < n4; k += blockDim.x)
+            d4[k] = s4[k];
+        done = n4 * 4u;
+    }
+    for (uint32_t k = done + threadIdx.x; k < s.row_bytes; k += blockDim.x)
+        dst[k] = src[k];
+}
+
+hipError_t launch_scatter_tiles(const ScatterArgs &s, hipStream_t stream) {
+    if (s.num_rows == 0 || s.row_bytes == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(pt_scatter_kernel, dim3(s.num_rows), dim3(256), 0, stream, s);
+    return hipGetLastError();
+}
+#endif
+
 hipError_t launch_trace(const SceneDesc &scene, const float *origins,
                         const float *directions, uint64_t n,
                         DeviceRayHit *hits, int scan, hipStream_t stream) {

@@ -50,3 +50,19 @@ PT_DECLARE_LAUNCHERS
 namespace pt_fast {
 PT_DECLARE_LAUNCHERS
 }
+
+namespace pt {
+// Multi-device gather (ptgpu_multi_render): `stage` holds G compact shards --
+// shard r at byte offset shard_offset[r], its local rows back to back -- and
+// every row goes to its place in the frame: tile t of `tile_rows` rows from
+// `row_begin` on belongs to shard t mod G.
+constexpr uint32_t kMaxShards = 64;
+struct ScatterArgs {
+    const uint8_t *stage;
+    uint8_t *frame;
+    uint32_t row_bytes;  // 3 * framew
+    uint32_t row_begin, num_rows, tile_rows, shards;
+    uint64_t shard_offset[kMaxShards];
+};
+hipError_t launch_scatter_tiles(const ScatterArgs &s, hipStream_t stream);
+} // namespace pt

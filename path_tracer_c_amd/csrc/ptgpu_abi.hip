@@ -17,6 +17,9 @@
 // unusable the explicit API returns PTGPU_ERR_NO_DEVICE and the void legacy
 // functions print the reason and abort().
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types and prototypes only: librccl is dlopen()ed on first use
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -1469,6 +1472,356 @@ int ptgpu_render_frame_multi(const scene *host_scene, uint8_t *frame,
             (void)hipStreamDestroy(shard[r].stream);
     }
     (void)hipSetDevice(home);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
+// one process, several GPUs, frame assembled in HBM on devices[0]
+// ---------------------------------------------------------------------------
+} // extern "C"
+
+namespace {
+
+// librccl, resolved at first use: hosts that never render across devices do
+// not load it, and a process in which PyTorch has already loaded its bundled
+// copy (same SONAME) shares that one.
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string why; // non-empty: could not be loaded
+};
+
+const Rccl &rccl() {
+    static const Rccl loaded = [] {
+        Rccl r;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib != nullptr)
+                break;
+        }
+        if (r.lib == nullptr) {
+            const char *e = dlerror();
+            r.why = std::string("librccl could not be loaded: ") + (e ? e : "?");
+            return r;
+        }
+        auto sym = [&](const char *name) {
+            void *p = dlsym(r.lib, name);
+            if (p == nullptr && r.why.empty())
+                r.why = std::string("librccl lacks ") + name;
+            return p;
+        };
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        return r;
+    }();
+    return loaded;
+}
+
+int fail_nccl(ncclResult_t e, const char *where) {
+    const Rccl &r = rccl();
+    return fail(PTGPU_ERR_HIP, std::string(where) + ": " +
+                                   (r.GetErrorString ? r.GetErrorString(e) : "RCCL error"));
+}
+
+struct DeviceBuffer {
+    uint8_t *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+// grows `b` on the CURRENT device
+int ensure(DeviceBuffer *b, size_t need) {
+    if (b->bytes >= need)
+        return PTGPU_OK;
+    if (b->ptr != nullptr)
+        (void)hipFree(b->ptr);
+    b->ptr = nullptr;
+    b->bytes = 0;
+    PT_TRY_HIP(hipMalloc(&b->ptr, need));
+    b->bytes = need;
+    return PTGPU_OK;
+}
+
+} // namespace
+
+struct ptgpu_multi {
+    std::vector<int> devices;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> rendered;    // shard r complete (peer-copy transport)
+    std::vector<ncclComm_t> comms;       // empty with the peer-copy transport
+    std::vector<ptgpu_scene *> scenes;
+    std::vector<DeviceBuffer> shards;    // on device r (r >= 1)
+    DeviceBuffer stage;                  // on devices[0]: every shard, back to back
+    bool use_rccl = false;
+    std::mutex lock;
+};
+
+extern "C" {
+
+void ptgpu_multi_destroy(ptgpu_multi *m) {
+    if (m == nullptr)
+        return;
+    int home = 0;
+    (void)hipGetDevice(&home);
+    for (size_t r = 0; r < m->devices.size(); ++r) {
+        (void)hipSetDevice(m->devices[r]);
+        if (r < m->streams.size() && m->streams[r])
+            (void)hipStreamSynchronize(m->streams[r]);
+        if (r < m->comms.size() && m->comms[r] && rccl().CommDestroy)
+            (void)rccl().CommDestroy(m->comms[r]);
+        if (r < m->scenes.size())
+            ptgpu_scene_free(m->scenes[r]);
+        if (r < m->shards.size() && m->shards[r].ptr)
+            (void)hipFree(m->shards[r].ptr);
+        if (r == 0 && m->stage.ptr)
+            (void)hipFree(m->stage.ptr);
+        if (r < m->rendered.size() && m->rendered[r])
+            (void)hipEventDestroy(m->rendered[r]);
+        if (r < m->streams.size() && m->streams[r])
+            (void)hipStreamDestroy(m->streams[r]);
+    }
+    (void)hipSetDevice(home);
+    delete m;
+}
+
+int ptgpu_multi_create(const int *devices, int n_devices, uint32_t flags, ptgpu_multi **out) {
+    if (out == nullptr)
+        return fail(PTGPU_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (devices == nullptr || n_devices <= 0 || n_devices > (int)pt::kMaxShards)
+        return fail(PTGPU_ERR_INVALID, "bad device list");
+    if (flags & ~PTGPU_MULTI_PEER_COPY)
+        return fail(PTGPU_ERR_INVALID, "unknown flag");
+    const int have = ptgpu_device_count();
+    if (have < 0)
+        return have;
+    for (int i = 0; i < n_devices; ++i)
+        if (devices[i] < 0 || devices[i] >= have)
+            return fail(PTGPU_ERR_INVALID, "device ordinal out of range");
+    const bool peer_copy = (flags & PTGPU_MULTI_PEER_COPY) != 0;
+    if (!peer_copy) {
+        // a communicator spans distinct devices, and a gather needs a peer
+        std::vector<int> sorted(devices, devices + n_devices);
+        std::sort(sorted.begin(), sorted.end());
+        const bool distinct = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
+        if (n_devices < 2 || !distinct)
+            return fail(PTGPU_ERR_LIMIT, "the RCCL gather needs at least two distinct devices "
+                                         "(PTGPU_MULTI_PEER_COPY rehearses on fewer)");
+        if (!rccl().why.empty())
+            return fail(PTGPU_ERR_NO_DEVICE, rccl().why);
+    }
+    ptgpu_multi *m = new (std::nothrow) ptgpu_multi();
+    if (m == nullptr)
+        return fail(PTGPU_ERR_NOMEM, "out of host memory");
+    m->devices.assign(devices, devices + n_devices);
+    m->streams.assign(n_devices, nullptr);
+    m->rendered.assign(n_devices, nullptr);
+    m->scenes.assign(n_devices, nullptr);
+    m->shards.assign(n_devices, DeviceBuffer());
+    m->use_rccl = !peer_copy;
+    int home = 0;
+    hipError_t e = hipGetDevice(&home);
+    for (int r = 0; r < n_devices && e == hipSuccess; ++r) {
+        e = hipSetDevice(devices[r]);
+        if (e == hipSuccess)
+            e = hipStreamCreateWithFlags(&m->streams[r], hipStreamNonBlocking);
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&m->rendered[r], hipEventDisableTiming);
+    }
+    int rc = e == hipSuccess ? PTGPU_OK : fail_hip(e, "multi-device setup");
+    if (rc == PTGPU_OK && m->use_rccl) {
+        m->comms.assign(n_devices, nullptr);
+        const ncclResult_t ne = rccl().CommInitAll(m->comms.data(), n_devices, devices);
+        if (ne != ncclSuccess)
+            rc = fail_nccl(ne, "ncclCommInitAll");
+    }
+    (void)hipSetDevice(home);
+    if (rc != PTGPU_OK) {
+        const std::string keep = g_last_error;
+        ptgpu_multi_destroy(m);
+        g_last_error = keep;
+        return rc;
+    }
+    *out = m;
+    return PTGPU_OK;
+}
+
+const char *ptgpu_multi_transport(const ptgpu_multi *m) {
+    return m == nullptr ? "" : (m->use_rccl ? "rccl" : "peer-copy");
+}
+
+int ptgpu_multi_upload(ptgpu_multi *m, const scene *host_scene) {
+    if (m == nullptr || host_scene == nullptr)
+        return fail(PTGPU_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> guard(m->lock);
+    int home = 0;
+    PT_TRY_HIP(hipGetDevice(&home));
+    int rc = PTGPU_OK;
+    for (size_t r = 0; r < m->devices.size() && rc == PTGPU_OK; ++r) {
+        hipError_t e = hipSetDevice(m->devices[r]);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(m->streams[r]); // the old copy may still be in use
+        if (e != hipSuccess) {
+            rc = fail_hip(e, "multi-device upload");
+            break;
+        }
+        ptgpu_scene_free(m->scenes[r]);
+        m->scenes[r] = nullptr;
+        rc = ptgpu_scene_upload(host_scene, &m->scenes[r]);
+    }
+    (void)hipSetDevice(home);
+    return rc;
+}
+
+int ptgpu_multi_render(ptgpu_multi *m, uint8_t *d_frame, size_t framew, size_t frameh,
+                       const ptgpu_params *p, uint32_t tile_rows) {
+    if (m == nullptr || d_frame == nullptr)
+        return fail(PTGPU_ERR_INVALID, "NULL argument");
+    ptgpu_params defaults;
+    if (p == nullptr) {
+        ptgpu_params_default(&defaults);
+        p = &defaults;
+    }
+    if (p->tile_rows != 0 || (p->flags & PTGPU_FLAG_COMPACT_ROWS))
+        return fail(PTGPU_ERR_INVALID, "the multi-device call shards the rows itself");
+    if (framew == 0 || frameh == 0 || p->row_begin >= frameh)
+        return fail(PTGPU_ERR_INVALID, "frame size or row_begin out of range");
+    const uint32_t first = p->row_begin;
+    const uint32_t rows = p->num_rows ? p->num_rows : (uint32_t)frameh - first;
+    if ((uint64_t)first + rows > frameh)
+        return fail(PTGPU_ERR_INVALID, "row set reaches below the frame");
+    std::lock_guard<std::mutex> guard(m->lock);
+    const uint32_t G = (uint32_t)m->devices.size();
+    for (uint32_t r = 0; r < G; ++r)
+        if (m->scenes[r] == nullptr)
+            return fail(PTGPU_ERR_INVALID, "no scene: call ptgpu_multi_upload first");
+    const uint32_t T = tile_rows ? tile_rows : 8u;
+    const uint32_t n_tiles = (rows + T - 1) / T;
+    const size_t row_bytes = 3u * framew;
+    if (row_bytes > 0xFFFFFFFFull)
+        return fail(PTGPU_ERR_LIMIT, "row too long");
+
+    // the deal: tile t -> shard t mod G; shard r's rows lie back to back at
+    // offset[r] of the staging buffer on devices[0] (16-byte aligned)
+    pt::ScatterArgs sa;
+    std::memset(&sa, 0, sizeof sa);
+    std::vector<uint32_t> shard_rows(G, 0);
+    size_t total = 0;
+    for (uint32_t r = 0; r < G; ++r) {
+        for (uint32_t t = r; t < n_tiles; t += G)
+            shard_rows[r] += (t + 1) * T <= rows ? T : rows - t * T;
+        sa.shard_offset[r] = total;
+        total += (row_bytes * shard_rows[r] + 15u) & ~(size_t)15u;
+    }
+
+    int home = 0;
+    PT_TRY_HIP(hipGetDevice(&home));
+    struct Restore {
+        int home;
+        ~Restore() { (void)hipSetDevice(home); }
+    } restore{home};
+
+    PT_TRY_HIP(hipSetDevice(m->devices[0]));
+    int rc = ensure(&m->stage, total ? total : 16);
+    // ---- every device renders its tiles (the devices overlap) -----------------
+    for (uint32_t r = 0; r < G && rc == PTGPU_OK; ++r) {
+        if (shard_rows[r] == 0)
+            continue;
+        PT_TRY_HIP(hipSetDevice(m->devices[r]));
+        uint8_t *dst = m->stage.ptr + sa.shard_offset[0];
+        if (r != 0) {
+            rc = ensure(&m->shards[r], row_bytes * shard_rows[r]);
+            if (rc != PTGPU_OK)
+                break;
+            dst = m->shards[r].ptr;
+        }
+        ptgpu_params q = *p;
+        q.row_begin = first + r * T;
+        q.num_rows = shard_rows[r];
+        q.tile_rows = T;
+        q.tile_stride = G;
+        q.flags |= PTGPU_FLAG_COMPACT_ROWS;
+        rc = render_common(m->scenes[r], dst, nullptr, framew, frameh, &q, m->streams[r]);
+        if (rc == PTGPU_OK && !m->use_rccl && r != 0)
+            PT_TRY_HIP(hipEventRecord(m->rendered[r], m->streams[r]));
+    }
+    // ---- ONE exchange: shards 1..G-1 -> devices[0] ---------------------------------
+    if (rc == PTGPU_OK && m->use_rccl) {
+        const Rccl &R = rccl();
+        ncclResult_t ne = R.GroupStart();
+        for (uint32_t r = 1; r < G && ne == ncclSuccess; ++r) {
+            if (shard_rows[r] == 0)
+                continue;
+            const size_t bytes = row_bytes * shard_rows[r];
+            ne = R.Send(m->shards[r].ptr, bytes, ncclUint8, 0, m->comms[r], m->streams[r]);
+            if (ne == ncclSuccess)
+                ne = R.Recv(m->stage.ptr + sa.shard_offset[r], bytes, ncclUint8, (int)r,
+                            m->comms[0], m->streams[0]);
+        }
+        const ncclResult_t ge = R.GroupEnd();
+        if (ne == ncclSuccess)
+            ne = ge;
+        if (ne != ncclSuccess)
+            rc = fail_nccl(ne, "grouped ncclSend/ncclRecv");
+    } else if (rc == PTGPU_OK) {
+        PT_TRY_HIP(hipSetDevice(m->devices[0]));
+        for (uint32_t r = 1; r < G; ++r) {
+            if (shard_rows[r] == 0)
+                continue;
+            PT_TRY_HIP(hipStreamWaitEvent(m->streams[0], m->rendered[r], 0));
+            PT_TRY_HIP(hipMemcpyPeerAsync(m->stage.ptr + sa.shard_offset[r], m->devices[0],
+                                          m->shards[r].ptr, m->devices[r],
+                                          row_bytes * shard_rows[r], m->streams[0]));
+        }
+    }
+    // ---- rows into place, on devices[0] --------------------------------------------
+    if (rc == PTGPU_OK) {
+        PT_TRY_HIP(hipSetDevice(m->devices[0]));
+        sa.stage = m->stage.ptr;
+        sa.frame = d_frame;
+        sa.row_bytes = (uint32_t)row_bytes;
+        sa.row_begin = first;
+        sa.num_rows = rows;
+        sa.tile_rows = T;
+        sa.shards = G;
+        const hipError_t e = pt::launch_scatter_tiles(sa, m->streams[0]);
+        if (e != hipSuccess)
+            rc = fail_hip(e, "scatter launch");
+    }
+    // the frame is complete when devices[0]'s stream is; the others are waited
+    // for too, so that their shard buffers may be reused by the next call
+    for (uint32_t r = 0; r < G; ++r) {
+        (void)hipSetDevice(m->devices[r]);
+        const hipError_t e = hipStreamSynchronize(m->streams[r]);
+        if (e != hipSuccess && rc == PTGPU_OK)
+            rc = fail_hip(e, "multi-device render");
+    }
+    return rc;
+}
+
+int ptgpu_render_device_multi(const scene *host_scene, uint8_t *d_frame_on_device0,
+                              size_t framew, size_t frameh, const ptgpu_params *p,
+                              const int *devices, int n_devices, uint32_t tile_rows) {
+    ptgpu_multi *m = nullptr;
+    int rc = ptgpu_multi_create(devices, n_devices, 0u, &m);
+    if (rc != PTGPU_OK)
+        return rc;
+    rc = ptgpu_multi_upload(m, host_scene);
+    if (rc == PTGPU_OK)
+        rc = ptgpu_multi_render(m, d_frame_on_device0, framew, frameh, p, tile_rows);
+    const std::string keep = g_last_error;
+    ptgpu_multi_destroy(m);
+    g_last_error = keep;
     return rc;
 }
 

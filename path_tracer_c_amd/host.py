@@ -237,6 +237,47 @@ class DeviceScene:
             pass
 
 
+class MultiDevice:
+    """ptgpu_multi_*: one process, several GPUs, the frame assembled in HBM on
+    devices[0] by one grouped ncclSend/ncclRecv (or, with peer_copy=True, by
+    peer copies: a rehearsal that also runs with repeated ordinals)."""
+
+    def __init__(self, devices, peer_copy=False):
+        self.handle = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        check(lib().ptgpu_multi_create(arr, len(devices),
+                                       _abi_flags_peer_copy() if peer_copy else 0,
+                                       C.byref(self.handle)))
+
+    @property
+    def transport(self) -> str:
+        return lib().ptgpu_multi_transport(self.handle).decode()
+
+    def upload(self, scene: HostScene):
+        check(lib().ptgpu_multi_upload(self.handle, scene.ptr()))
+        return self
+
+    def render(self, d_frame_ptr: int, width: int, height: int, params: Params, tile_rows=0):
+        check(lib().ptgpu_multi_render(self.handle, C.c_void_p(d_frame_ptr), width, height,
+                                       C.byref(params), tile_rows))
+
+    def close(self):
+        if self.handle:
+            lib().ptgpu_multi_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def _abi_flags_peer_copy():
+    from ._abi import MULTI_PEER_COPY
+    return MULTI_PEER_COPY
+
+
 def resolve(d_accum_ptr: int, d_frame_ptr: int, npixels: int, stream: int = 0):
     check(lib().ptgpu_resolve_device(C.c_void_p(d_accum_ptr),
                                      C.c_void_p(d_frame_ptr), npixels,
