@@ -28,7 +28,7 @@ FASTFLAGS := $(filter-out -ffp-contract=off -fhip-fp32-correctly-rounded-divide-
              -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -DPT_FAST_MATH -DPT_NS=pt_fast $(EXTRA_FASTFLAGS)
 
 HOST_OBJS := $(BUILD)/scene.o $(BUILD)/vector.o $(BUILD)/bitmap.o $(BUILD)/scenes.o
-HIP_OBJS  := $(BUILD)/pt_kernels.o $(BUILD)/pt_kernels_fast.o $(BUILD)/ptgpu_abi.o
+HIP_OBJS  := $(BUILD)/pt_kernels.o $(BUILD)/pt_kernels_fast.o $(BUILD)/pt_glsl.o $(BUILD)/ptgpu_abi.o
 DEV_HDRS  := $(wildcard $(CSRC)/device/*.h) $(wildcard $(CSRC)/*.hpp) $(wildcard include/*.h)
 
 all: $(LIBDIR)/libptgpu.so oracle bin/ptrender
@@ -40,6 +40,9 @@ $(BUILD)/%.o: $(CSRC)/host/%.c include/path_tracer_api.h include/ptgpu.h | $(BUI
 	$(CC) $(CFLAGS) -c $< -o $@
 
 $(BUILD)/pt_kernels.o: $(CSRC)/device/pt_kernels.hip $(DEV_HDRS) | $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(BUILD)/pt_glsl.o: $(CSRC)/device/pt_glsl.hip $(DEV_HDRS) | $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(BUILD)/pt_kernels_fast.o: $(CSRC)/device/pt_kernels.hip $(DEV_HDRS) | $(BUILD)
@@ -76,9 +79,10 @@ asan-driver: | $(BUILD) bin
 	$(HIPCC) $(filter-out -O3,$(HIPFLAGS)) -O1 -g $(ASAN_HOST) -c $(CSRC)/ptgpu_abi.hip -o $(BUILD)/asan_abi.o
 	$(HIPCC) $(filter-out -O3,$(HIPFLAGS)) -O1 -g -c $(CSRC)/device/pt_kernels.hip -o $(BUILD)/asan_kernels.o
 	$(HIPCC) $(filter-out -O3,$(FASTFLAGS)) -O1 -g -c $(CSRC)/device/pt_kernels.hip -o $(BUILD)/asan_kernels_fast.o
+	$(HIPCC) $(filter-out -O3,$(HIPFLAGS)) -O1 -g -c $(CSRC)/device/pt_glsl.hip -o $(BUILD)/asan_glsl.o
 	for f in scene vector bitmap scenes main; do \
 	  $(CLANG) -std=gnu2x -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -ffp-contract=off -Iinclude \
 	    -c $(CSRC)/host/$$f.c -o $(BUILD)/asan_$$f.o || exit 1; done
 	$(HIPCC) --offload-arch=$(ARCH) -fno-gpu-sanitize -fsanitize=address,undefined -o bin/ptrender_asan \
 	  $(BUILD)/asan_main.o $(BUILD)/asan_scene.o $(BUILD)/asan_vector.o $(BUILD)/asan_bitmap.o $(BUILD)/asan_scenes.o \
-	  $(BUILD)/asan_abi.o $(BUILD)/asan_kernels.o $(BUILD)/asan_kernels_fast.o -lpthread -lm
+	  $(BUILD)/asan_abi.o $(BUILD)/asan_kernels.o $(BUILD)/asan_kernels_fast.o $(BUILD)/asan_glsl.o -lpthread -lm

@@ -119,6 +119,26 @@ extern "C" {
                                          the bit.  Also accepted in the
                                          scan_flags of the trace_rays calls */
 
+#define PTGPU_FLAG_GLSL_SEMANTICS 0x2000u /* NOT scheduling only -- render by the
+                                         rules of the reference's OTHER renderer,
+                                         its OpenGL fragment shader
+                                         (shaders/rtx_frag.glsl), where they differ
+                                         from src/renderer.c: PCG stream carried
+                                         across a pixel's samples (`seed` = the
+                                         shader's random_seed uniform), Box-Muller
+                                         rand_unit_sphere, roughness not halved,
+                                         the material's refractive_index, total
+                                         internal reflection drops the transmitted
+                                         ray only, rays through pixel centres, no
+                                         per-sample clamp, round-to-nearest RGB8.
+                                         ptgpu_render_device / _frame only (no
+                                         accumulator, sample_offset 0), at most
+                                         PTGPU_MAX_BOUNCES_TREE bounces.  Checked
+                                         against a CPU restatement of the shader
+                                         (oracle/pt_glsl.c): bit-equal where no
+                                         random number is consumed, to a stated
+                                         tolerance otherwise (log / cos) */
+
 /* limits */
 #define PTGPU_MAX_BOUNCES_PATH 62 /* non-branching kernel (LDS material stack) */
 #define PTGPU_MAX_BOUNCES_TREE 14 /* branching kernel (per-lane frame stack) */

@@ -62,4 +62,22 @@ PTGPU_HD float ptgpu_u32_to_unit(uint32_t x) {
     return (float)(x >> 8) * 0x1.0p-24f;
 }
 
+/* ---- the OpenGL renderer's stream (PTGPU_FLAG_GLSL_SEMANTICS only) ----------
+ * shaders/rtx_frag.glsl:64-75: PCG hash; one uint state per PIXEL, started at
+ * pixel_idx + random_seed, bumped by the sample index at the start of every
+ * sample and carried from sample to sample (`rng_state += sample_id`,
+ * :277-278,289) -- so a pixel's samples must be traced in order. */
+PTGPU_HD uint32_t ptgpu_pcg_next(uint32_t *state) {
+    *state = *state * 747796405u + 2891336453u;
+    uint32_t result = ((*state >> ((*state >> 28) + 4u)) ^ *state) * 277803737u;
+    result = (result >> 22) ^ result;
+    return result;
+}
+
+/* `next_random(state) / 4294967295.0` (:73-75): uint -> float (to nearest), divided
+ * by the float nearest to 2^32 - 1, which is 2^32; can be exactly 1. */
+PTGPU_HD float ptgpu_pcg_unit(uint32_t *state) {
+    return (float)ptgpu_pcg_next(state) / 4294967296.0f;
+}
+
 #endif /* PTGPU_RNG_H */

@@ -71,6 +71,10 @@ def lib():
                                        C.c_size_t, C.c_size_t, C.c_size_t,
                                        C.c_size_t, C.POINTER(OracleParams),
                                        C.c_uint]
+        h.oracle_glsl_render_rows.restype = C.c_uint64
+        h.oracle_glsl_render_rows.argtypes = [C.POINTER(Scene), C.c_void_p, C.c_void_p,
+                                              C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                                              C.c_uint32, C.c_uint32, C.c_float, C.c_uint32]
         _lib = h
     return _lib
 
@@ -118,6 +122,22 @@ def render_mt(scene, width, height, threads, row_begin=0, row_end=None,
                                   width, height, row_begin, row_end, row_step,
                                   C.byref(p), threads)
     return frame, int(rays)
+
+
+def glsl_render_rows(scene, width, height, row_begin=0, row_end=None, spp=16, max_bounces=4,
+                     fov_rad=None, seed=1, want_mean=False):
+    """The shader restatement (oracle/pt_glsl.c): (frame, mean or None, rays)."""
+    if row_end is None:
+        row_end = height
+    if fov_rad is None:
+        fov_rad = float(np.float32(np.pi / 180.0 * 90.0))
+    frame = np.zeros((height, width, 3), dtype=np.uint8)
+    mean = np.zeros((height, width, 3), dtype=np.float32) if want_mean else None
+    rays = lib().oracle_glsl_render_rows(
+        scene.ptr(), frame.ctypes.data_as(C.c_void_p),
+        mean.ctypes.data_as(C.c_void_p) if want_mean else None, width, height, row_begin, row_end,
+        spp, max_bounces, fov_rad, seed)
+    return frame, mean, int(rays)
 
 
 def trace_rays(scene, origins, directions):

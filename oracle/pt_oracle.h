@@ -61,4 +61,11 @@ uint64_t oracle_render_mt(const scene *world, uint8_t *frame, size_t w,
                           size_t row_step, const oracle_params *p,
                           unsigned int num_threads);
 
+/* The reference's OTHER renderer, shaders/rtx_frag.glsl, restated (pt_glsl.c):
+ * the checker of PTGPU_FLAG_GLSL_SEMANTICS.  Rows [row_begin, row_end), row 0 =
+ * top; `mean` (may be NULL): unclamped per-pixel means, 3 floats per pixel. */
+uint64_t oracle_glsl_render_rows(const scene *world, uint8_t *frame, float *mean, size_t w, size_t h,
+                                 size_t row_begin, size_t row_end, uint32_t spp, uint32_t max_bounces,
+                                 float fov_rad, uint32_t random_seed);
+
 #endif /* ORACLE_PT_ORACLE_H */

@@ -42,6 +42,7 @@ FLAG_SCAN_BVH = 0x400
 FLAG_SCAN_SCREENED = 0x20
 FLAG_WHOLE_WALKS = 0x800
 FLAG_FAST_MATH = 0x1000
+FLAG_GLSL_SEMANTICS = 0x2000
 MULTI_PEER_COPY = 0x1
 
 MAX_BOUNCES_PATH = 62

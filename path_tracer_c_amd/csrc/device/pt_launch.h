@@ -65,4 +65,6 @@ struct ScatterArgs {
     uint64_t shard_offset[kMaxShards];
 };
 hipError_t launch_scatter_tiles(const ScatterArgs &s, hipStream_t stream);
+// PTGPU_FLAG_GLSL_SEMANTICS: one frame's rows by the shader's rules (pt_glsl.hip)
+hipError_t launch_glsl(const LaunchArgs &a, hipStream_t stream);
 } // namespace pt

@@ -36,6 +36,7 @@
 namespace pt {
 
 constexpr uint32_t kMetaMaterialMask = 0x7FFFFFFFu;
+constexpr uint32_t kGlslMaxBounces = 14; // pt_glsl.hip keeps a ray stack of this + 2 per lane
 
 struct F4 { // plain 16-byte record usable on host and device
     float x, y, z, w;
@@ -48,6 +49,9 @@ struct SceneDesc {
     const F4 *mat;        // 2 * n_mat
     const uint32_t *meta; // n_obj
     const uint32_t *link; // n_obj
+    const F4 *mat_extra;  // n_mat: roughness (not halved), refractive_index, 0, 0 --
+                          // read by the GLSL-semantics kernel only (pt_glsl.hip);
+                          // behind the blob the LDS copy takes
     // optional hierarchy over the objects (csrc/bvh_build.hpp); n_nodes == 0
     // when it was not built
     const F4 *bvh_nodes;           // 4 * n_nodes (inner nodes, child boxes inside)

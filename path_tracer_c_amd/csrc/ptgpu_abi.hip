@@ -331,7 +331,9 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
     }
 
     const size_t bytes = pt::scene_lds_bytes(n_obj, n_tri, n_mat);
-    std::vector<unsigned char> blob(bytes ? bytes : 16, 0);
+    // (+ one record per material behind the part the LDS copy takes: mat_extra)
+    std::vector<unsigned char> blob((bytes ? bytes : 16) + (size_t)16 * n_mat, 0);
+    pt::F4 *mat_extra = reinterpret_cast<pt::F4 *>(blob.data() + (bytes ? bytes : 16));
     pt::F4 *geom = reinterpret_cast<pt::F4 *>(blob.data());
     pt::F4 *tri = geom + n_obj;
     pt::F4 *mat = tri + 4u * (size_t)n_tri;
@@ -375,6 +377,7 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
         mat[2 * m + 0] = pt::F4{s.albedo.x, s.albedo.y, s.albedo.z,
                                 (float)((double)s.roughness * 0.5)};
         mat[2 * m + 1] = pt::F4{le.x, le.y, le.z, s.transparency};
+        mat_extra[m] = pt::F4{s.roughness, s.refractive_index, 0.0f, 0.0f};
         if (s.transparency > 0.0f && s.transparency < 1.0f)
             branching = 1;
     }
@@ -405,6 +408,8 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
                                                       4u * (size_t)n_tri +
                                                       2u * (size_t)n_mat);
     h->desc.link = h->desc.meta + n_obj;
+    h->desc.mat_extra = reinterpret_cast<const pt::F4 *>(
+        static_cast<const unsigned char *>(h->blob) + (bytes ? bytes : 16));
     h->desc.bvh_nodes = nullptr;
     h->desc.bvh_order = nullptr;
     h->desc.bvh_unbounded = nullptr;
@@ -879,6 +884,28 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         return rc;
     const uint64_t npix = (uint64_t)a.num_rows * a.framew;
     const uint32_t total_spp = a.spp;
+    if (p->flags & PTGPU_FLAG_GLSL_SEMANTICS) {
+        // the shader's rules (pt_glsl.hip): its random stream is one state per
+        // pixel carried from sample to sample, so a frame is one launch of all
+        // its samples, from sample 0, straight to RGB8
+        if (d_frame == nullptr)
+            return fail(PTGPU_ERR_INVALID, "GLSL semantics: no accumulator form (the shader's "
+                                           "stream is carried across a pixel's samples)");
+        if (p->sample_offset != 0)
+            return fail(PTGPU_ERR_INVALID, "GLSL semantics: sample_offset must be 0");
+        if (p->max_bounces > pt::kGlslMaxBounces)
+            return fail(PTGPU_ERR_LIMIT, "GLSL semantics: max_bounces exceeds the ray stack");
+        if (p->flags & PTGPU_FLAG_FAST_MATH)
+            return fail(PTGPU_ERR_INVALID, "GLSL semantics has no tolerance build");
+        TimedCall timed_glsl(a.counters != nullptr, stream);
+        a.frame = d_frame;
+        const hipError_t e = pt::launch_glsl(a, stream);
+        if (e != hipSuccess)
+            return fail_hip(e, "GLSL-semantics launch");
+        count_launch();
+        timed_glsl.add_bytes(3ull * npix);
+        return PTGPU_OK;
+    }
     const Launchers &L = *launchers_for(p->flags);
     TimedCall timed(a.counters != nullptr, stream); // part of the statistics
 

@@ -1453,3 +1453,94 @@ def test_multi_device_rccl_gather_equals_the_single_launch_frame(gpu):
     run = subprocess.run([sys.executable, str(root / "tools" / "multi_rccl_check.py")],
                          capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout + run.stderr
+
+
+# ---- PTGPU_FLAG_GLSL_SEMANTICS: the reference's shader renderer ----
+def _glsl_scene_without_roughness(gpu, triangles):
+    """Mirrors, glass of three refractive indices, half-transparent glass, lamps --
+    and no roughness anywhere, so no random number reaches the picture."""
+    s = gpu.HostScene()
+    s.set_sky(0.35, 0.55, 0.9)
+    lamp = s.add_material((0.9, 0.8, 0.1), roughness=0.0, emission_color=(1.0, 0.9, 0.7), emission_strength=2.5)
+    mirror = s.add_material((0.9, 0.9, 0.95), roughness=0.0)
+    glass13 = s.add_material((1, 1, 1), roughness=0.0, transparency=1.0, refractive_index=1.3)
+    glass18 = s.add_material((0.9, 1, 0.9), roughness=0.0, transparency=1.0, refractive_index=1.8)
+    half = s.add_material((1, 0.8, 0.8), roughness=0.0, transparency=0.5, refractive_index=1.5)
+    floor = s.add_material((0.5, 0.5, 0.5), roughness=0.0)
+    s.add_sphere((6, 6, 12), 3.0, lamp)
+    s.add_sphere((-2.2, 0.1, 6), 1.2, mirror)
+    s.add_sphere((0.4, -0.3, 4.5), 0.8, glass13)
+    s.add_sphere((2.4, 0.2, 6.5), 1.1, glass18)
+    s.add_sphere((0.0, 1.8, 7.0), 0.9, half)
+    if triangles:
+        s.add_triangle((-30, -1.2, -5), (30, -1.2, -5), (30, -1.2, 40), floor)
+        s.add_triangle((-30, -1.2, -5), (-30, -1.2, 40), (30, -1.2, 40), floor)
+    else:
+        s.add_sphere((0, -501.2, 8), 500.0, floor)
+    return s
+
+
+@pytest.mark.parametrize("triangles", [False, True])
+def test_glsl_semantics_frames_without_randomness_are_bit_equal_to_the_shader_oracle(gpu, oracle, triangles):
+    w, h = 120, 80
+    with _glsl_scene_without_roughness(gpu, triangles) as s:
+        for spp, b in ((1, 4), (3, 6)):
+            got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=99,
+                                   flags=gpu._abi.FLAG_GLSL_SEMANTICS)
+            ref, _, rays = oracle.glsl_render_rows(s, w, h, spp=spp, max_bounces=b, seed=99)
+            assert np.array_equal(got, ref), (triangles, spp, b)
+        gpu.host.reset_stats()
+        gpu.render_frame(s, w, h, spp=3, max_bounces=6, seed=99, flags=gpu._abi.FLAG_GLSL_SEMANTICS)
+        st = gpu.host.read_stats()
+        assert st.rays == rays and st.samples == w * h * 3      # the branching stack, ray for ray
+        # and it is another renderer than the default one
+        cpu_rules = gpu.render_frame(s, w, h, spp=3, max_bounces=6, seed=99)
+        assert not np.array_equal(cpu_rules, got)
+
+
+@pytest.mark.parametrize("cfg,w,h,spp,b", [(0, 160, 100, 32, 4), (1, 96, 96, 32, 4), (2, 96, 54, 32, 8),
+                                           (5, 64, 36, 8, 6)])
+def test_glsl_semantics_rough_frames_are_bit_equal_to_the_shader_oracle(gpu, oracle, cfg, w, h, spp, b):
+    """Scenes with roughness consume the Box-Muller stream.  Its log and cos are
+    a shared specification (include/ptgpu_glsl_math.h: sequentially rounded
+    binary32 kernels, no library call), so the frames are held to the oracle
+    bit for bit here too -- which matters: the shader's own quadratic on a
+    radius-1000 sphere cancels catastrophically (rtx_frag.glsl:105-113), half
+    the rays leaving such a wall re-hit it at distance ~0 depending on the last
+    bit, and with libm's logf / cosf on one side and the device's on the other
+    configuration 2's frames were 60 levels RMSE apart."""
+    with gpu.HostScene(cfg) as s:
+        got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=5,
+                               flags=gpu._abi.FLAG_GLSL_SEMANTICS)
+        ref = oracle.glsl_render_rows(s, w, h, spp=spp, max_bounces=b, seed=5)[0]
+    assert np.array_equal(got, ref)
+
+
+def test_glsl_semantics_row_sets_and_argument_handling(gpu, torch_cuda):
+    A = gpu._abi
+    w, h = 64, 40
+    kw = dict(spp=4, max_bounces=4, seed=3)
+    with gpu.HostScene(0) as s, gpu.DeviceScene(s) as d:
+        full = render_device(gpu, torch_cuda, d, w, h, flags=A.FLAG_GLSL_SEMANTICS, **kw)
+        part = render_device(gpu, torch_cuda, d, w, h, row_begin=8, num_rows=16,
+                             flags=A.FLAG_GLSL_SEMANTICS | A.FLAG_COMPACT_ROWS, **kw)
+        assert np.array_equal(part, full[8:24])          # a pixel's stream does not depend on the row set
+        tiled = render_device(gpu, torch_cuda, d, w, h, row_begin=2, num_rows=12, tile_rows=2, tile_stride=3,
+                              flags=A.FLAG_GLSL_SEMANTICS | A.FLAG_COMPACT_ROWS, **kw)
+        rows = [2 + (i // 2) * 6 + i % 2 for i in range(12)]
+        assert np.array_equal(tiled, full[rows])
+        acc = torch_cuda.zeros((h, w, 4), dtype=torch_cuda.float32, device="cuda")
+        L = gpu.lib()
+        p = gpu.make_params(flags=A.FLAG_GLSL_SEMANTICS, **kw)
+        assert L.ptgpu_accumulate_device(d.handle, C.c_void_p(acc.data_ptr()), w, h, C.byref(p),
+                                         None) == A.PTGPU_ERR_INVALID
+        out = torch_cuda.zeros((h, w, 3), dtype=torch_cuda.uint8, device="cuda")
+        p = gpu.make_params(flags=A.FLAG_GLSL_SEMANTICS, sample_offset=4, **kw)
+        assert L.ptgpu_render_device(d.handle, C.c_void_p(out.data_ptr()), w, h, C.byref(p),
+                                     None) == A.PTGPU_ERR_INVALID
+        p = gpu.make_params(flags=A.FLAG_GLSL_SEMANTICS, spp=1, max_bounces=15)
+        assert L.ptgpu_render_device(d.handle, C.c_void_p(out.data_ptr()), w, h, C.byref(p),
+                                     None) == A.PTGPU_ERR_LIMIT
+        p = gpu.make_params(flags=A.FLAG_GLSL_SEMANTICS | A.FLAG_FAST_MATH, **kw)
+        assert L.ptgpu_render_device(d.handle, C.c_void_p(out.data_ptr()), w, h, C.byref(p),
+                                     None) == A.PTGPU_ERR_INVALID
