@@ -232,8 +232,21 @@ int ptgpu_scene_scan(const ptgpu_scene *s);
  * longest chain of them.  Both 0 when the scene has none. */
 int ptgpu_scene_hierarchy(const ptgpu_scene *s, uint32_t *nodes, uint32_t *depth);
 
+/* Measures, once, which scan form (plain / screened / BVH), which schedule
+ * (pixel owner / sample queue) and how many lanes per pixel suit this scene on
+ * this device: timed pilot renders of a framew x frameh frame with `p` (NULL =
+ * defaults at 64 spp) into a scratch frame.  SYNCHRONOUS.  The result is
+ * remembered in the scene (and, by content, for later uploads of the same
+ * scene) and never changes an image.  The asynchronous entry points below do
+ * NOT measure: an untuned scene goes by object count (plain < 32 <= screened
+ * < 96 <= BVH + sample queue), which is right for most and up to ~7 % off the
+ * measured choice on configuration 2.  The synchronous ones (ptgpu_render_frame,
+ * the legacy shims) tune on a scene's first large frame by themselves.  Too
+ * small a frame (< 2^22 samples, < 16 spp) measures nothing and returns OK. */
+int ptgpu_scene_tune(const ptgpu_scene *s, size_t framew, size_t frameh, const ptgpu_params *p);
+
 /* -- rendering ------------------------------------------------------------- */
-/* Asynchronous: renders the row set of `p` of a framew x frameh image into
+/* Asynchronous (never synchronises the stream; see ptgpu_scene_tune): renders the row set of `p` of a framew x frameh image into
  * `d_frame` (device memory, RGB8, 3*framew bytes per row) on `hip_stream`
  * (a hipStream_t, NULL = default stream).  Bytes written equal, bit for bit,
  * what the reference's render_task would store for the same stream of random

@@ -204,6 +204,7 @@ SIGNATURES = {
     "ptgpu_scene_scan": (C.c_int, [C.c_void_p]),
     "ptgpu_scene_hierarchy": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ptgpu_release_scratch": (C.c_int, []),
+    "ptgpu_scene_tune": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(Params)]),
     "ptgpu_render_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t,
                                       C.c_size_t, C.POINTER(Params), C.c_void_p]),
     "ptgpu_render_frame": (C.c_int, [C.POINTER(Scene), C.c_void_p, C.c_size_t,

@@ -1065,6 +1065,12 @@ hipError_t launch_primary(const LaunchArgs &a, float *primary_hits, hipStream_t 
         return hipSuccess;
     const uint32_t grid = (uint32_t)((npix + 255u) / 256u);
     const size_t lds = (size_t)4 * 256u * (kScreenQueue + a.scene.bvh_depth + 2u);
+    if (lds > 64u * 1024u) { // a hierarchy deeper than 50 levels
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pt_primary_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+    }
     hipLaunchKernelGGL(pt_primary_kernel, dim3(grid), dim3(256), lds, stream, a,
                        reinterpret_cast<float2 *>(primary_hits));
     return hipGetLastError();
@@ -1169,6 +1175,14 @@ hipError_t launch_trace(const SceneDesc &scene, const float *origins,
     // scan), doubling as the waves' staging areas (10 rows)
     const uint32_t rows = scan == 0 ? 10u : kScreenQueue + scene.bvh_depth + 2u;
     const size_t lds = (size_t)4 * 256u * rows;
+    if (lds > 64u * 1024u) { // a hierarchy deeper than 50 levels
+        const void *kernel = scan == 2   ? reinterpret_cast<const void *>(pt_trace_kernel<2>)
+                             : scan == 1 ? reinterpret_cast<const void *>(pt_trace_kernel<1>)
+                                         : reinterpret_cast<const void *>(pt_trace_kernel<0>);
+        hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+    }
     if (scan == 2)
         hipLaunchKernelGGL(pt_trace_kernel<2>, dim3(grid), dim3(256), lds, stream,
                            scene, origins, directions, n, hits);

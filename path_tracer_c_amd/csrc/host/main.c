@@ -26,6 +26,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <time.h>
 
 #define WIDTH 1280 /* src/main.c:17-18 */
@@ -42,6 +43,48 @@ static uint32_t env_number(const char *name, uint32_t fallback) {
     return (v && *v) ? (uint32_t)strtoul(v, NULL, 0) : fallback;
 }
 
+/* What a snapshot belongs to: a resumed render must continue THE SAME render.
+ * (FNV-1a over the scene's arrays: any edit of an object or material shows.) */
+static uint64_t fnv1a(const void *data, size_t n, uint64_t h) {
+    const unsigned char *p = data;
+    for (size_t i = 0; i < n; i++) {
+        h ^= p[i];
+        h *= 0x100000001B3ull;
+    }
+    return h;
+}
+
+typedef struct {
+    uint64_t magic, width, height, samples_done;
+    uint64_t scene_hash;
+    uint32_t seed, max_bounces, fov_bits, flags;
+} snapshot_head;
+#define SNAPSHOT_MAGIC 0x32544E5350475450ull /* "PTGPSNT2" */
+
+static snapshot_head snapshot_of(const scene *world, size_t width, size_t height,
+                                 const ptgpu_params *p, uint32_t done) {
+    snapshot_head h;
+    memset(&h, 0, sizeof h);
+    h.magic = SNAPSHOT_MAGIC;
+    h.width = width;
+    h.height = height;
+    h.samples_done = done;
+    uint64_t x = 0xCBF29CE484222325ull;
+    x = fnv1a(&world->num_objects, sizeof world->num_objects, x);
+    x = fnv1a(&world->num_materials, sizeof world->num_materials, x);
+    x = fnv1a(&world->sky_color, sizeof world->sky_color, x);
+    if (world->num_objects)
+        x = fnv1a(world->objects, world->num_objects * sizeof(shape), x);
+    if (world->num_materials)
+        x = fnv1a(world->materials, world->num_materials * sizeof(shape_material), x);
+    h.scene_hash = x;
+    h.seed = p->seed;
+    h.max_bounces = p->max_bounces;
+    memcpy(&h.fov_bits, &p->fov_rad, sizeof h.fov_bits);
+    h.flags = p->flags & (PTGPU_FLAG_FAST_MATH | PTGPU_FLAG_GLSL_SEMANTICS); /* what changes a sample */
+    return h;
+}
+
 static int progressive(scene *world, size_t width, size_t height, char *path,
                        uint32_t per_pass) {
     ptgpu_params p;
@@ -55,25 +98,43 @@ static int progressive(scene *world, size_t width, size_t height, char *path,
     int rc = ptgpu_scene_upload(world, &dev);
     if (rc == PTGPU_OK) rc = ptgpu_device_alloc(16 * npix, &d_accum);
     if (rc == PTGPU_OK) rc = ptgpu_device_alloc(3 * npix, &d_frame);
+    int status = 1;
     if (rc != PTGPU_OK || frame == NULL || accum == NULL) {
         fprintf(stderr, "progressive setup failed: %s\n", ptgpu_last_error());
-        return 1;
+        goto cleanup;
     }
 
-    /* resume: header {width, height, samples done} + the float4 accumulator */
+    /* resume: a header that says WHICH render the sums belong to (frame size,
+     * scene content, seed, bounce limit, field of view, arithmetic mode) +
+     * the float4 accumulator.  A snapshot of another render is refused, not
+     * added to. */
     uint32_t done = 0;
     const char *resume = getenv("PTGPU_RESUME");
     if (resume && *resume) {
         FILE *in = fopen(resume, "rb");
-        uint64_t head[3];
-        if (in && fread(head, sizeof head, 1, in) == 1 && head[0] == width &&
-            head[1] == height && head[2] <= total &&
-            fread(accum, 16, npix, in) == npix) {
-            done = (uint32_t)head[2];
-            ptgpu_device_upload(d_accum, accum, 16 * npix);
-            printf("resumed %s at %u of %u spp\n", resume, done, total);
+        if (in) {
+            snapshot_head have, want = snapshot_of(world, width, height, &p, 0);
+            if (fread(&have, sizeof have, 1, in) != 1 || have.magic != SNAPSHOT_MAGIC) {
+                fprintf(stderr, "%s is not a snapshot of this program: starting over\n", resume);
+            } else {
+                want.samples_done = have.samples_done;
+                if (memcmp(&have, &want, sizeof have) != 0 || have.samples_done > total) {
+                    fprintf(stderr, "%s belongs to another render (frame size, scene, seed, "
+                                    "bounces, field of view or mode differ): refusing to "
+                                    "continue it\n", resume);
+                    fclose(in);
+                    goto cleanup;
+                }
+                if (fread(accum, 16, npix, in) == npix &&
+                    ptgpu_device_upload(d_accum, accum, 16 * npix) == PTGPU_OK) {
+                    done = (uint32_t)have.samples_done;
+                    printf("resumed %s at %u of %u spp\n", resume, done, total);
+                } else {
+                    fprintf(stderr, "%s is truncated: starting over\n", resume);
+                }
+            }
+            fclose(in);
         }
-        if (in) fclose(in);
     }
     uint32_t stop_after = env_number("PTGPU_STOP_AFTER", total); /* for tests */
 
@@ -86,27 +147,40 @@ static int progressive(scene *world, size_t width, size_t height, char *path,
         if (rc == PTGPU_OK) rc = ptgpu_device_download(frame, d_frame, 3 * npix);
         if (rc != PTGPU_OK) {
             fprintf(stderr, "pass failed: %s\n", ptgpu_last_error());
-            return 1;
+            goto cleanup;
         }
         done += p.spp;
         write_bitmap(path, (unsigned int)width, (unsigned int)height, frame, true);
         printf("%u/%u spp  %.3f s\n", done, total, seconds_now() - t0);
     }
     if (resume && *resume && ptgpu_device_download(accum, d_accum, 16 * npix) == PTGPU_OK) {
-        FILE *out = fopen(resume, "wb");
-        uint64_t head[3] = {width, height, done};
-        if (out) {
-            fwrite(head, sizeof head, 1, out);
-            fwrite(accum, 16, npix, out);
-            fclose(out);
+        /* written beside the old snapshot and renamed over it: a crash while
+         * writing leaves the previous one intact */
+        size_t n = strlen(resume) + 5;
+        char *tmp = malloc(n);
+        if (tmp != NULL) {
+            snprintf(tmp, n, "%s.tmp", resume);
+            FILE *out = fopen(tmp, "wb");
+            const snapshot_head head = snapshot_of(world, width, height, &p, done);
+            int ok = out != NULL && fwrite(&head, sizeof head, 1, out) == 1 &&
+                     fwrite(accum, 16, npix, out) == npix;
+            if (out != NULL && fclose(out) != 0)
+                ok = 0;
+            if (!ok || rename(tmp, resume) != 0) {
+                fprintf(stderr, "could not write snapshot %s\n", resume);
+                remove(tmp);
+            }
+            free(tmp);
         }
     }
+    status = 0;
+cleanup:
     ptgpu_device_free(d_accum);
     ptgpu_device_free(d_frame);
     ptgpu_scene_free(dev);
     free(frame);
     free(accum);
-    return 0;
+    return status;
 }
 
 int main(int argc, char **argv) {

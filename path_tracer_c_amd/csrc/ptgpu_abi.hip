@@ -873,9 +873,14 @@ enum Mode { kPixelOwner = 0, kSampleQueue = 1 };
 // `d_frame` (fused render: RGB8 out) and `d_accum` (caller's accumulator) is
 // non-null.  Every path below adds the samples of a pixel in sample order, so
 // they all produce the same bits; they differ in schedule only.
+// `may_pilot`: an unmeasured scene may be measured inside this call (timed pilot
+// passes that synchronise the stream a few times).  The synchronous entry
+// points (host frames, the legacy shims, ptgpu_scene_tune) allow it; the
+// asynchronous device-frame entry points do not, and go by object count until
+// the scene has been tuned.
 int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
                   size_t framew, size_t frameh, const ptgpu_params *p,
-                  hipStream_t stream) {
+                  hipStream_t stream, bool may_pilot) {
     pt::LaunchArgs a;
     uint32_t block = 0;
     bool tree = false;
@@ -917,7 +922,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         mode = kSampleQueue;
     if (tree)
         mode = kPixelOwner; // the branching kernel exists in pixel-owner form only
-    const bool can_measure = a.counters != nullptr && !tree && total_spp >= 16 &&
+    const bool can_measure = may_pilot && a.counters != nullptr && !tree && total_spp >= 16 &&
                              npix * total_spp >= (1ull << 22);
     if (mode < 0 && !can_measure) // (the BVH scan is at its best in queue form)
         mode = (a.screened == 2u && !tree) ? kSampleQueue : kPixelOwner;
@@ -1149,15 +1154,17 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
             double ms = 0.0, rays = 0.0, samples = 0.0, lane_passes = 0.0;
         } tally[3];
         hipEvent_t ev[2] = {nullptr, nullptr};
-        PT_TRY_HIP(hipEventCreate(&ev[0]));
-        PT_TRY_HIP(hipEventCreate(&ev[1]));
-        struct DropEvents {
+        struct DropEvents { // (in place before the first create: neither can leak)
             hipEvent_t *ev;
             ~DropEvents() {
-                (void)hipEventDestroy(ev[0]);
-                (void)hipEventDestroy(ev[1]);
+                if (ev[0] != nullptr)
+                    (void)hipEventDestroy(ev[0]);
+                if (ev[1] != nullptr)
+                    (void)hipEventDestroy(ev[1]);
             }
         } drop_events{ev};
+        PT_TRY_HIP(hipEventCreate(&ev[0]));
+        PT_TRY_HIP(hipEventCreate(&ev[1]));
         if (accum_is_zero) {
             PT_TRY_HIP(hipMemsetAsync(accum, 0, (size_t)npix * 16u, stream));
             accum_is_zero = false;
@@ -1285,7 +1292,7 @@ int ptgpu_render_device(const ptgpu_scene *s, uint8_t *d_frame, size_t framew,
     if (d_frame == nullptr)
         return fail(PTGPU_ERR_INVALID, "d_frame is NULL");
     return render_common(s, d_frame, nullptr, framew, frameh, p,
-                         (hipStream_t)hip_stream);
+                         (hipStream_t)hip_stream, false);
 }
 
 int ptgpu_accumulate_device(const ptgpu_scene *s, float *d_accum,
@@ -1296,7 +1303,30 @@ int ptgpu_accumulate_device(const ptgpu_scene *s, float *d_accum,
     if ((reinterpret_cast<uintptr_t>(d_accum) & 15u) != 0)
         return fail(PTGPU_ERR_INVALID, "d_accum must be 16-byte aligned");
     return render_common(s, nullptr, d_accum, framew, frameh, p,
-                         (hipStream_t)hip_stream);
+                         (hipStream_t)hip_stream, false);
+}
+
+int ptgpu_scene_tune(const ptgpu_scene *s, size_t framew, size_t frameh, const ptgpu_params *p) {
+    if (s == nullptr)
+        return fail(PTGPU_ERR_INVALID, "scene is NULL");
+    ptgpu_params defaults;
+    if (p == nullptr) {
+        ptgpu_params_default(&defaults);
+        defaults.spp = 64;
+        p = &defaults;
+    }
+    if (framew == 0 || frameh == 0 || framew * frameh > 0xFFFFFFFFull)
+        return fail(PTGPU_ERR_INVALID, "frame size out of range");
+    uint8_t *scratch = nullptr;
+    PT_TRY_HIP(hipMalloc(&scratch, 3u * framew * frameh));
+    ptgpu_params q = *p;
+    q.flags &= ~(uint32_t)PTGPU_FLAG_COMPACT_ROWS;
+    int rc = render_common(s, scratch, nullptr, framew, frameh, &q, nullptr, true);
+    const hipError_t e = hipDeviceSynchronize();
+    (void)hipFree(scratch);
+    if (rc == PTGPU_OK && e != hipSuccess)
+        rc = fail_hip(e, "scene tune");
+    return rc;
 }
 
 int ptgpu_resolve_device(const float *d_accum, uint8_t *d_frame,
@@ -1328,8 +1358,10 @@ struct RowBuffer {
 };
 RowBuffer g_row_buffers[kMaxDevices];
 
+// `dest_compact`: `frame` is a shard buffer (local row i at row i) instead of
+// a whole frame (local row i at its global row).
 int render_frame_with(const ptgpu_scene *s, uint8_t *frame, size_t framew,
-                      size_t frameh, const ptgpu_params *p) {
+                      size_t frameh, const ptgpu_params *p, bool dest_compact = false) {
     ptgpu_params q = *p;
     q.flags |= PTGPU_FLAG_COMPACT_ROWS;
     pt::LaunchArgs a; // only for the row map and sizes
@@ -1364,7 +1396,7 @@ int render_frame_with(const ptgpu_scene *s, uint8_t *frame, size_t framew,
     } else {
         PT_TRY_HIP(hipMalloc(&d_rows, bytes));
     }
-    rc = render_common(s, d_rows, nullptr, framew, frameh, &q, nullptr);
+    rc = render_common(s, d_rows, nullptr, framew, frameh, &q, nullptr, true);
     hipError_t e = hipSuccess;
     if (rc == PTGPU_OK)
         e = hipDeviceSynchronize();
@@ -1375,7 +1407,7 @@ int render_frame_with(const ptgpu_scene *s, uint8_t *frame, size_t framew,
         uint32_t j = i + 1;
         while (j < a.num_rows && global_row(a, j) == global_row(a, j - 1) + 1)
             ++j;
-        e = hipMemcpy(frame + row_bytes * global_row(a, i),
+        e = hipMemcpy(frame + row_bytes * (dest_compact ? i : global_row(a, i)),
                       d_rows + row_bytes * i, row_bytes * (j - i),
                       hipMemcpyDeviceToHost);
         i = j;
@@ -1473,7 +1505,7 @@ int ptgpu_render_frame_multi(const scene *host_scene, uint8_t *frame,
         q.tile_stride = G;
         q.flags |= PTGPU_FLAG_COMPACT_ROWS;
         rc = render_common(shard[r].scene, shard[r].rows, nullptr, framew, frameh,
-                           &q, shard[r].stream);
+                           &q, shard[r].stream, true);
     }
     for (uint32_t r = 0; r < G; ++r) {
         if (shard[r].num_rows == 0)
@@ -1778,7 +1810,7 @@ int ptgpu_multi_render(ptgpu_multi *m, uint8_t *d_frame, size_t framew, size_t f
         q.tile_rows = T;
         q.tile_stride = G;
         q.flags |= PTGPU_FLAG_COMPACT_ROWS;
-        rc = render_common(m->scenes[r], dst, nullptr, framew, frameh, &q, m->streams[r]);
+        rc = render_common(m->scenes[r], dst, nullptr, framew, frameh, &q, m->streams[r], true);
         if (rc == PTGPU_OK && !m->use_rccl && r != 0)
             PT_TRY_HIP(hipEventRecord(m->rendered[r], m->streams[r]));
     }
@@ -1915,14 +1947,8 @@ int ptgpu_trace_rays_scan(const scene *host_scene, const float *origins,
     int rc = ptgpu_scene_upload(host_scene, &s);
     if (rc != PTGPU_OK)
         return rc;
-    float *d_o = nullptr, *d_d = nullptr;
-    pt::DeviceRayHit *d_h = nullptr;
-    const size_t vec_bytes = 3u * sizeof(float) * n;
-    hipError_t e = hipMalloc(&d_o, vec_bytes);
-    if (e == hipSuccess) e = hipMalloc(&d_d, vec_bytes);
-    if (e == hipSuccess) e = hipMalloc(&d_h, sizeof(pt::DeviceRayHit) * n);
-    if (e == hipSuccess) e = hipMemcpy(d_o, origins, vec_bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_d, directions, vec_bytes, hipMemcpyHostToDevice);
+    // (the scan form is settled before anything is allocated: no buffer to
+    // lose on this error path)
     int scan = 0;
     if (scan_flags & PTGPU_FLAG_SCAN_SCREENED)
         scan = 1;
@@ -1933,6 +1959,14 @@ int ptgpu_trace_rays_scan(const scene *host_scene, const float *origins,
         }
         scan = 2;
     }
+    float *d_o = nullptr, *d_d = nullptr;
+    pt::DeviceRayHit *d_h = nullptr;
+    const size_t vec_bytes = 3u * sizeof(float) * n;
+    hipError_t e = hipMalloc(&d_o, vec_bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_d, vec_bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_h, sizeof(pt::DeviceRayHit) * n);
+    if (e == hipSuccess) e = hipMemcpy(d_o, origins, vec_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_d, directions, vec_bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess)
         e = launchers_for(scan_flags)->trace(s->desc, d_o, d_d, n, d_h, scan, nullptr);
     if (e == hipSuccess)
@@ -2034,16 +2068,17 @@ int ptgpu_release_scratch(void) {
     if (rc != PTGPU_OK)
         return rc;
     DeviceScratch &sc = g_scratch[dev];
-    std::lock_guard<std::mutex> guard(sc.lock);
+    RowBuffer &keep = g_row_buffers[dev];
+    // One order everywhere: the row buffer's lock before the scratch lock
+    // (render_frame_with holds the former for the whole call and render_common
+    // takes the latter inside it); std::scoped_lock also avoids the deadlock by
+    // construction.
+    std::scoped_lock both(keep.lock, sc.lock);
     PT_TRY_HIP(hipDeviceSynchronize());
-    {
-        RowBuffer &keep = g_row_buffers[dev];
-        std::lock_guard<std::mutex> rows_guard(keep.lock);
-        if (keep.rows != nullptr)
-            (void)hipFree(keep.rows);
-        keep.rows = nullptr;
-        keep.bytes = 0;
-    }
+    if (keep.rows != nullptr)
+        (void)hipFree(keep.rows);
+    keep.rows = nullptr;
+    keep.bytes = 0;
     if (sc.samples)
         (void)hipFree(sc.samples);
     if (sc.accum)
@@ -2130,7 +2165,8 @@ ptgpu_scene *legacy_scene(const scene *w) {
 }
 
 void legacy_render_rows(const scene *world, uint8_t *frame, size_t framew,
-                        size_t frameh, uint32_t row_begin, uint32_t num_rows) {
+                        size_t frameh, uint32_t row_begin, uint32_t num_rows,
+                        bool dest_compact = false) {
     std::lock_guard<std::mutex> guard(g_cache_mutex);
     ptgpu_params p;
     ptgpu_params_from_env(&p);
@@ -2139,7 +2175,7 @@ void legacy_render_rows(const scene *world, uint8_t *frame, size_t framew,
     p.tile_rows = 0;
     p.tile_stride = 1;
     uint32_t n_dev = 0;
-    if (env_u32("PTGPU_DEVICES", &n_dev) && n_dev > 1 && num_rows >= 2 * n_dev) {
+    if (!dest_compact && env_u32("PTGPU_DEVICES", &n_dev) && n_dev > 1 && num_rows >= 2 * n_dev) {
         int have = ptgpu_device_count();
         if (have < 1)
             die("device count");
@@ -2154,7 +2190,7 @@ void legacy_render_rows(const scene *world, uint8_t *frame, size_t framew,
         return;
     }
     ptgpu_scene *s = legacy_scene(world);
-    if (render_frame_with(s, frame, framew, frameh, &p) != PTGPU_OK)
+    if (render_frame_with(s, frame, framew, frameh, &p, dest_compact) != PTGPU_OK)
         die("render");
 }
 
@@ -2167,13 +2203,110 @@ struct PoolTask {
 
 } // namespace
 
+// ---------------------------------------------------------------------------
+// render_task called DIRECTLY (not through the pool shim): a caller with its
+// own loop or its own threads asks for one row per call, and a launch plus a
+// device-to-host copy per row is 1080 serialised round trips per 1080p frame.
+// The row must be in the caller's frame when the call returns (that is the
+// function's contract, src/renderer.c:92-116), so work cannot be put off; it
+// can be done AHEAD: when calls walk the rows in order, the next miss renders
+// twice as many rows as the last one (1, 2, 4, ... up to the rest of the
+// frame) into a host-side cache, and the calls that follow are a memcpy.  A
+// row is a pure function of (scene content, settings, frame size, row), which
+// is the cache's key -- a caller that edits its scene between calls gets fresh
+// rows.  A 1080-row frame costs 11 launches instead of 1080; once a frame has
+// been walked to its end the next one is fetched whole.  PTGPU_LEGACY_READAHEAD=0
+// turns it off (one row per call, as before).
+// ---------------------------------------------------------------------------
+namespace {
+
+struct RowCache {
+    const scene *world = nullptr;
+    uint64_t hash = 0;
+    size_t framew = 0, frameh = 0;
+    ptgpu_params params;          // settings the rows were rendered with
+    uint32_t row_begin = 0, num_rows = 0;
+    std::vector<uint8_t> rows;    // num_rows * 3 * framew bytes
+    uint32_t batch = 1;           // rows fetched by the last miss
+    bool walked_to_the_end = false; // the last frame of this key was walked sequentially
+    bool valid = false;
+};
+RowCache g_row_cache;
+std::mutex g_row_cache_mutex; // held for a whole direct call; taken BEFORE g_cache_mutex
+                              // (which legacy_render_rows takes inside)
+
+bool same_settings(const ptgpu_params &a, const ptgpu_params &b) {
+    return a.spp == b.spp && a.max_bounces == b.max_bounces && a.seed == b.seed &&
+           __builtin_bit_cast(uint32_t, a.fov_rad) == __builtin_bit_cast(uint32_t, b.fov_rad) &&
+           a.sample_offset == b.sample_offset &&
+           (a.flags & (PTGPU_FLAG_FAST_MATH | PTGPU_FLAG_GLSL_SEMANTICS)) ==
+               (b.flags & (PTGPU_FLAG_FAST_MATH | PTGPU_FLAG_GLSL_SEMANTICS));
+}
+
+bool readahead_enabled() {
+    static const bool on = [] {
+        uint32_t v = 1;
+        env_u32("PTGPU_LEGACY_READAHEAD", &v);
+        return v != 0;
+    }();
+    return on;
+}
+
+void legacy_one_row(const scene *world, uint8_t *frame, size_t framew, size_t frameh, uint32_t y) {
+    if (!readahead_enabled()) {
+        legacy_render_rows(world, frame, framew, frameh, y, 1u);
+        return;
+    }
+    const size_t row_bytes = 3u * framew;
+    ptgpu_params now;
+    ptgpu_params_from_env(&now);
+    const uint64_t h = scene_hash(world);
+    RowCache &c = g_row_cache;
+    std::lock_guard<std::mutex> guard(g_row_cache_mutex);
+    const bool same_key = c.valid && c.world == world && c.hash == h && c.framew == framew &&
+                          c.frameh == frameh && same_settings(c.params, now);
+    if (same_key && y >= c.row_begin && y < c.row_begin + c.num_rows) {
+        std::memcpy(frame + row_bytes * y, c.rows.data() + row_bytes * (y - c.row_begin), row_bytes);
+        if (y + 1 == frameh)
+            c.walked_to_the_end = true;
+        return;
+    }
+    // a miss: how far ahead?  Twice the last batch when this row continues the
+    // walk (just past the cached rows); the whole frame when the last frame of
+    // this key was walked to its end and this one starts at the top
+    uint32_t ahead = 1;
+    if (same_key && y == c.row_begin + c.num_rows)
+        ahead = c.batch < (1u << 30) ? 2u * c.batch : c.batch;
+    else if (same_key && c.walked_to_the_end && y == 0)
+        ahead = (uint32_t)frameh;
+    if ((uint64_t)y + ahead > frameh)
+        ahead = (uint32_t)(frameh - y);
+    c.valid = false;
+    c.world = world;
+    c.hash = h;
+    c.framew = framew;
+    c.frameh = frameh;
+    c.params = now;
+    c.row_begin = y;
+    c.num_rows = ahead;
+    c.batch = ahead;
+    c.walked_to_the_end = false;
+    c.rows.resize(row_bytes * ahead);
+    legacy_render_rows(world, c.rows.data(), framew, frameh, y, ahead, /*dest_compact=*/true);
+    c.valid = true;
+    std::memcpy(frame + row_bytes * y, c.rows.data(), row_bytes);
+    if (y + 1 == frameh)
+        c.walked_to_the_end = true;
+}
+
+} // namespace
+
 void render_task(render_args *arg) {
     if (arg == nullptr || arg->frame == nullptr || arg->world == nullptr)
         return;
     if (arg->screen_y < 0 || (size_t)arg->screen_y >= arg->frameh)
         return;
-    legacy_render_rows(arg->world, arg->frame, arg->framew, arg->frameh,
-                       (uint32_t)arg->screen_y, 1u);
+    legacy_one_row(arg->world, arg->frame, arg->framew, arg->frameh, (uint32_t)arg->screen_y);
 }
 
 ray_hit trace_ray(const vec3s origin, const vec3s direction,

@@ -198,6 +198,12 @@ class DeviceScene:
         check(lib().ptgpu_scene_hierarchy(self.handle, C.byref(nodes), C.byref(depth)))
         return nodes.value, depth.value
 
+    def tune(self, width: int, height: int, params: Params | None = None):
+        """ptgpu_scene_tune: measure scan form / schedule once (synchronous)."""
+        check(lib().ptgpu_scene_tune(self.handle, width, height,
+                                     C.byref(params) if params is not None else None))
+        return self
+
     def trace(self, d_origins_ptr: int, d_directions_ptr: int, n: int, d_hits_ptr: int,
               scan_flags: int = 0, stream: int = 0):
         """ptgpu_trace_rays_device: n x 3 float origins / directions and n

@@ -548,9 +548,10 @@ def test_sample_queue_in_several_passes_and_on_a_shard(gpu, torch_cuda, oracle, 
 
 
 def test_schedule_is_measured_once_per_scene_and_cached(gpu, torch_cuda):
-    """With neither schedule flag, the first large render of a scene measures
-    lane utilisation (1000 spheres under an open sky -> sample queue) and later
-    renders reuse the choice; all of them give the same frame."""
+    """ptgpu_scene_tune measures a scene once (1000 spheres under an open sky ->
+    sample queue); the asynchronous entry point never measures -- before the
+    tune it goes by object count, afterwards by the remembered choice -- and
+    every one of these renders gives the same frame."""
     torch = torch_cuda
     w, h, spp = 512, 512, 32
     kw = dict(spp=spp, max_bounces=4, seed=4)
@@ -560,16 +561,20 @@ def test_schedule_is_measured_once_per_scene_and_cached(gpu, torch_cuda):
         with gpu.DeviceScene(s) as d:
             owner = render_device(gpu, torch, d, w, h, flags=0x80, **kw)
             gpu.host.reset_stats()
-            first = render_device(gpu, torch, d, w, h, **kw)      # pilots + remainder
-            n_first = gpu.host.read_stats().launches
+            untuned = render_device(gpu, torch, d, w, h, **kw)    # asynchronous: no pilots
+            n_untuned = gpu.host.read_stats().launches
+            assert d.scan == "by object count"
+            gpu.host.reset_stats()
+            d.tune(w, h, gpu.make_params(**kw))                   # pilots + remainder, synchronous
+            n_tune = gpu.host.read_stats().launches
             gpu.host.reset_stats()
             second = render_device(gpu, torch, d, w, h, **kw)     # remembered choice
             n_second = gpu.host.read_stats().launches
             schedule, scan = d.schedule, d.scan
         with gpu.DeviceScene(s) as again:                         # same content, new handle
             assert (again.schedule, again.scan) == (schedule, scan)
-    assert np.array_equal(first, owner) and np.array_equal(second, owner)
-    assert n_first > n_second                     # the pilot launches happened once
+    assert np.array_equal(untuned, owner) and np.array_equal(second, owner)
+    assert n_tune > n_second and n_untuned == n_second     # the pilot launches happened once, in the tune
     assert schedule == "sample-queue" and scan in ("screened linear", "bvh")
 
 
@@ -1251,6 +1256,8 @@ def test_full_size_config5_256_spp_against_the_oracle(gpu, torch_cuda, oracle):
     kw = dict(spp=c["spp"], max_bounces=c["max_bounces"], seed=c["seed"])
     gpu.host.reset_stats()
     with gpu.HostScene(c["scene"]) as s, gpu.DeviceScene(s) as d:
+        d.tune(w, h, gpu.make_params(**kw))
+        gpu.host.reset_stats()
         frame = render_device(gpu, torch_cuda, d, w, h, **kw)
         st = gpu.host.read_stats()
         assert st.samples == w * h * c["spp"]
@@ -1544,3 +1551,118 @@ def test_glsl_semantics_row_sets_and_argument_handling(gpu, torch_cuda):
         p = gpu.make_params(flags=A.FLAG_GLSL_SEMANTICS | A.FLAG_FAST_MATH, **kw)
         assert L.ptgpu_render_device(d.handle, C.c_void_p(out.data_ptr()), w, h, C.byref(p),
                                      None) == A.PTGPU_ERR_INVALID
+
+
+# ---- round 2: direct render_task calls, scratch release beside renders, snapshot identity ----
+def _direct_rows(gpu, scene, w, h, rows, frame=None):
+    """render_task called directly, one row per call (no pool)."""
+    L, A = gpu.lib(), gpu._abi
+    if frame is None:
+        frame = np.zeros((h, w, 3), dtype=np.uint8)
+    args = A.RenderArgs()
+    args.framew, args.frameh = w, h
+    args.frame = frame.ctypes.data_as(C.POINTER(C.c_uint8))
+    args.world = C.pointer(scene.c)
+    for y in rows:
+        args.screen_y = y
+        L.render_task(C.byref(args))
+    return frame
+
+
+def test_direct_render_task_calls_read_ahead_and_stay_exact(gpu, oracle, monkeypatch):
+    """A caller that loops over render_task itself gets each row when its call
+    returns (the contract), but the library renders AHEAD: 1, 2, 4, ... rows per
+    launch while the calls walk the rows in order, the whole frame at once for
+    the next frame -- 7 launches for 48 rows, then 1, instead of 48 each.  Rows
+    asked for out of order, or after the scene was edited, are rendered afresh."""
+    monkeypatch.setenv("PTGPU_SPP", "6")
+    monkeypatch.setenv("PTGPU_BOUNCES", "4")
+    monkeypatch.setenv("PTGPU_SEED", "11")
+    w, h = 64, 48
+    with gpu.HostScene(0) as s:
+        ref, _ = oracle.render_rows(s, w, h, spp=6, max_bounces=4, seed=11)
+        gpu.host.reset_stats()
+        first = _direct_rows(gpu, s, w, h, range(h))
+        n_first = gpu.host.read_stats().launches
+        gpu.host.reset_stats()
+        second = _direct_rows(gpu, s, w, h, range(h))
+        n_second = gpu.host.read_stats().launches
+        assert np.array_equal(first, ref) and np.array_equal(second, ref)
+        assert n_first <= 7 and n_second == 1, (n_first, n_second)
+        # bottom-up, and a scattered order: every call still returns its own row
+        assert np.array_equal(_direct_rows(gpu, s, w, h, range(h - 1, -1, -1)), ref)
+        order = list(np.random.default_rng(3).permutation(h))
+        assert np.array_equal(_direct_rows(gpu, s, w, h, order), ref)
+        # the scene is edited half-way down the frame: the rows below are the new scene's
+        frame = _direct_rows(gpu, s, w, h, range(0, 24))
+        s.c.objects[1].sphere.radius = 1.75
+        _direct_rows(gpu, s, w, h, range(24, h), frame=frame)
+        ref2, _ = oracle.render_rows(s, w, h, spp=6, max_bounces=4, seed=11)
+        assert np.array_equal(frame[:24], ref[:24]) and np.array_equal(frame[24:], ref2[24:])
+        assert not np.array_equal(ref[24:], ref2[24:])
+        # other settings (the environment is read on every call): other rows
+        monkeypatch.setenv("PTGPU_SEED", "12")
+        ref3, _ = oracle.render_rows(s, w, h, spp=6, max_bounces=4, seed=12)
+        assert np.array_equal(_direct_rows(gpu, s, w, h, range(h)), ref3)
+
+
+def test_scratch_release_beside_host_frame_renders_does_not_deadlock(gpu):
+    """ptgpu_release_scratch while other threads render host frames through the
+    scratch accumulator (sample queue): one lock order (row buffer before
+    scratch), so neither side can wait for the other forever."""
+    import threading
+    stop = threading.Event()
+    errors = []
+    with gpu.HostScene(2) as s:
+        ref = gpu.render_frame(s, 96, 54, spp=8, max_bounces=8, seed=2, flags=0x100)
+
+        def render():
+            try:
+                for _ in range(25):
+                    got = gpu.render_frame(s, 96, 54, spp=8, max_bounces=8, seed=2, flags=0x100)
+                    if not np.array_equal(got, ref):
+                        errors.append("frame differs")
+            except Exception as exc:                       # pragma: no cover
+                errors.append(repr(exc))
+
+        def release():
+            while not stop.is_set():
+                if gpu.lib().ptgpu_release_scratch() != 0:
+                    errors.append("release failed")        # pragma: no cover
+                    return
+
+        workers = [threading.Thread(target=render) for _ in range(2)]
+        freer = threading.Thread(target=release)
+        for t in workers + [freer]:
+            t.start()
+        for t in workers:
+            t.join(120)
+        stop.set()
+        freer.join(30)
+        assert not any(t.is_alive() for t in workers + [freer]), "deadlock"
+    assert not errors, errors
+
+
+def test_progressive_driver_refuses_a_snapshot_of_another_render(gpu, tmp_path):
+    """PTGPU_RESUME: the snapshot says which render it belongs to (frame size,
+    scene content, seed, bounce limit, field of view); resuming with anything
+    else is refused instead of adding new samples onto stale sums, and the
+    snapshot is replaced by rename, never rewritten in place."""
+    import subprocess
+    exe = Path(__file__).resolve().parent.parent / "bin" / "ptrender"
+    w, h = 40, 30
+    base = dict(os.environ, PTGPU_SPP="12", PTGPU_BOUNCES="4", PTGPU_SEED="9", PTGPU_PROGRESSIVE="4")
+    out, acc = tmp_path / "p.bmp", tmp_path / "p.acc"
+    run = lambda env, cfg="1", ww=w: subprocess.run([str(exe), cfg, str(ww), str(h), str(out)], env=env,
+                                                    capture_output=True, text=True, timeout=120)
+    r1 = run(dict(base, PTGPU_RESUME=str(acc), PTGPU_STOP_AFTER="4"))
+    assert r1.returncode == 0 and acc.exists() and not (tmp_path / "p.acc.tmp").exists()
+    kept = acc.read_bytes()
+    for env, cfg, ww in ((dict(base, PTGPU_SEED="10"), "1", w), (dict(base, PTGPU_BOUNCES="5"), "1", w),
+                         (base, "0", w), (base, "1", w + 2), (dict(base, PTGPU_FOV_DEG="60"), "1", w)):
+        r = run(dict(env, PTGPU_RESUME=str(acc)), cfg, ww)
+        assert r.returncode == 1 and "another render" in r.stderr, r.stdout + r.stderr
+        assert acc.read_bytes() == kept
+    acc.write_bytes(b"not a snapshot")
+    r = run(dict(base, PTGPU_RESUME=str(acc)))
+    assert r.returncode == 0 and "not a snapshot" in r.stderr and "12/12 spp" in r.stdout
