@@ -40,6 +40,89 @@ constexpr uint32_t kLeafMax = PT_LEAF_MAX;
 
 constexpr uint32_t kBvhLeafBit = 0x80000000u;
 
+// ---- binary16 boxes for the device ------------------------------------------
+// The walk is bound by the vector-memory path (64 bytes per clock per CU): a
+// wave's inner-node step fetched 64 bytes per lane.  The device copy of a node
+// therefore holds its two child boxes in binary16, rounded OUTWARD (lower
+// corners toward -infinity, upper corners toward +infinity, beyond 65504 to
+// +-infinity), which only ever enlarges a box -- by 2^-11 of a coordinate at
+// most -- so the set of objects that reach the exact test can only grow, never
+// lose one.  32 bytes per node, two 16-byte records:
+//     {L.lo.x|L.lo.y, L.lo.z|L.hi.x, L.hi.y|L.hi.z, L.ref}  {R..., R.ref}
+inline uint16_t half_magnitude(double a, bool away_from_zero) {
+    if (!(a == a))
+        return 0x7E00u;
+    if (std::isinf(a))
+        return 0x7C00u;
+    if (a > 65504.0)
+        return away_from_zero ? 0x7C00u : 0x7BFFu;
+    if (a < 6.103515625e-05) { // below 2^-14: subnormal halves, steps of 2^-24
+        const double n = a * 16777216.0;
+        uint32_t k = (uint32_t)n;
+        if (away_from_zero && n > (double)k)
+            ++k;
+        return (uint16_t)k; // 1024 = the smallest normal half: the encodings join up
+    }
+    int e = 0;
+    const double m = std::frexp(a, &e) * 2.0; // a = m * 2^(e-1), m in [1, 2)
+    e -= 1;
+    const double q = (m - 1.0) * 1024.0;
+    uint32_t k = (uint32_t)q;
+    if (away_from_zero && q > (double)k)
+        ++k;
+    if (k == 1024u) {
+        k = 0;
+        ++e;
+    }
+    if (e > 15)
+        return 0x7C00u;
+    return (uint16_t)(((uint32_t)(e + 15) << 10) | k);
+}
+
+// x rounded to a binary16 value that is <= x (up = false) or >= x (up = true)
+inline uint16_t half_directed(float x, bool up) {
+    const bool negative = std::signbit(x);
+    const uint16_t mag = half_magnitude(std::fabs((double)x), negative ? !up : up);
+    return (uint16_t)(mag | (negative ? 0x8000u : 0u));
+}
+
+inline float half_value(uint16_t h) { // for the self-tests
+    const uint32_t e = (h >> 10) & 31u, k = h & 1023u;
+    double v;
+    if (e == 0)
+        v = std::ldexp((double)k, -24);
+    else if (e == 31)
+        v = k ? std::numeric_limits<double>::quiet_NaN() : std::numeric_limits<double>::infinity();
+    else
+        v = std::ldexp(1.0 + (double)k / 1024.0, (int)e - 15);
+    return (float)((h & 0x8000u) ? -v : v);
+}
+
+// 4 float records per node (L.lo|ref, L.hi, R.lo|ref, R.hi) -> 2 packed records
+inline std::vector<F4> pack_nodes_half(const std::vector<F4> &nodes) {
+    auto bits = [](float f) {
+        uint32_t u;
+        std::memcpy(&u, &f, sizeof u);
+        return u;
+    };
+    auto as_float = [](uint32_t u) {
+        float f;
+        std::memcpy(&f, &u, sizeof f);
+        return f;
+    };
+    std::vector<F4> out(nodes.size() / 2);
+    for (size_t n = 0; n + 3 < nodes.size(); n += 4) {
+        for (int child = 0; child < 2; ++child) {
+            const F4 &lo = nodes[n + 2 * child], &hi = nodes[n + 2 * child + 1];
+            const uint32_t a = half_directed(lo.x, false) | ((uint32_t)half_directed(lo.y, false) << 16);
+            const uint32_t b = half_directed(lo.z, false) | ((uint32_t)half_directed(hi.x, true) << 16);
+            const uint32_t c = half_directed(hi.y, true) | ((uint32_t)half_directed(hi.z, true) << 16);
+            out[n / 2 + child] = F4{as_float(a), as_float(b), as_float(c), as_float(bits(lo.w))};
+        }
+    }
+    return out;
+}
+
 struct BvhHost {
     std::vector<F4> nodes;           // 4 records per inner node
     std::vector<uint32_t> order;     // object indices, leaf runs

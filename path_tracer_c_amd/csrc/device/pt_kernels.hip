@@ -73,6 +73,7 @@ __device__ __forceinline__ SceneRecords records_in_global_memory(const SceneDesc
     rec.n_obj = scene.n_obj;
     rec.bvh_nodes = scene.bvh_nodes;
     rec.bvh_order = scene.bvh_order;
+    rec.bvh_leaf_geom = scene.bvh_leaf_geom;
     rec.bvh_unbounded = scene.bvh_unbounded;
     rec.n_nodes = scene.n_nodes;
     rec.n_unbounded = scene.n_unbounded;
@@ -117,7 +118,7 @@ stage_scene(const LaunchArgs &a, uint4 *lds_dyn, uint32_t tid, uint32_t nthreads
         w.rec.link = w.rec.meta + n_obj;
         lds_used16 = blob16;
         if (a.screened == 2u) { // the hierarchy's nodes ride along
-            const uint32_t node16 = 4u * a.scene.n_nodes;
+            const uint32_t node16 = 2u * a.scene.n_nodes;
             const uint4 *nsrc = reinterpret_cast<const uint4 *>(a.scene.bvh_nodes);
             for (uint32_t i = tid; i < node16; i += nthreads)
                 lds_dyn[lds_used16 + i] = nsrc[i];
@@ -135,6 +136,7 @@ stage_scene(const LaunchArgs &a, uint4 *lds_dyn, uint32_t tid, uint32_t nthreads
                                 (scene_lds_bytes(n_obj, n_tri, n_mat) / 16u)
                           : a.scene.bvh_nodes;
     w.rec.bvh_order = a.scene.bvh_order;
+    w.rec.bvh_leaf_geom = a.scene.bvh_leaf_geom;
     w.rec.bvh_unbounded = a.scene.bvh_unbounded;
     w.rec.n_nodes = a.scene.n_nodes;
     w.rec.n_unbounded = a.scene.n_unbounded;
@@ -606,6 +608,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
 #endif
 #ifdef PT_BVH_PROFILE
     uint32_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#elif defined(PT_STAMPS)
+    unsigned long long quantum_stamps[3] = {0, 0, 0}; // inner steps, leaf visits, exact tests
+    uint32_t *const prof = reinterpret_cast<uint32_t *>(quantum_stamps);
 #else
     uint32_t *const prof = nullptr;
 #endif
@@ -712,7 +717,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
         }
         ++iters;
         PT_STAMP(q0);
-        bvh_walk_quantum(w.rec, w.queue, p.o, p.d, st == kWalk, a.walk_budget, walk, prof);
+        bvh_walk_quantum(w.rec, w.queue, p.o, p.d, st == kWalk, a.walk_budget, a.leaf_lanes,
+                         a.resolve_lanes, walk, prof);
         PT_STAMP(q1);
         PT_STAMP_ADD(t_walk, q1, q0);
     }
@@ -725,6 +731,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)
             atomicAdd(&g_stamps[2], t_settle);
             atomicAdd(&g_stamps[3], k_end - k_begin);
             atomicAdd(&g_stamps[4], t_refill);
+            atomicAdd(&g_stamps[5], quantum_stamps[0]);
+            atomicAdd(&g_stamps[6], quantum_stamps[1]);
+            atomicAdd(&g_stamps[7], quantum_stamps[2]);
         }
     }
 #endif
@@ -950,7 +959,7 @@ size_t megakernel_lds_bytes(const LaunchArgs &a, uint32_t block, bool tree) {
     if (a.scene_in_lds) {
         bytes += scene_lds_bytes(a.scene.n_obj, a.scene.n_tri, a.scene.n_mat);
         if (a.screened == 2u)
-            bytes += (size_t)64 * a.scene.n_nodes;
+            bytes += (size_t)32 * a.scene.n_nodes;
     }
     // (the branching kernel keeps its frames in private memory and leaves the
     // bounce stack unused, but shares the layout)

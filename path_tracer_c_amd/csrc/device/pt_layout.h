@@ -54,8 +54,12 @@ struct SceneDesc {
                           // behind the blob the LDS copy takes
     // optional hierarchy over the objects (csrc/bvh_build.hpp); n_nodes == 0
     // when it was not built
-    const F4 *bvh_nodes;           // 4 * n_nodes (inner nodes, child boxes inside)
+    const F4 *bvh_nodes;           // 2 * n_nodes: both child boxes in binary16, rounded
+                                   // outward, + the child refs (csrc/bvh_build.hpp)
     const uint32_t *bvh_order;     // object indices, leaf runs
+    const F4 *bvh_leaf_geom;       // geom[bvh_order[j]] copied into leaf order: a leaf's
+                                   // records lie side by side and are fetched together
+                                   // (both arrays are padded by a leaf's worth of slots)
     const uint32_t *bvh_unbounded; // objects without a finite box
     uint32_t n_nodes;
     uint32_t n_unbounded;
@@ -112,6 +116,8 @@ struct LaunchArgs {
     uint32_t chunk_batch;   // sample queue: chunks a wave reserves per atomic
     uint32_t stream_walks;  // sample queue + BVH scan: resumable walks (pt_streamkernel)
     uint32_t walk_budget;   // ... inner-node steps per quantum
+    uint32_t leaf_lanes;    // ... lanes standing on a leaf before leaves are visited
+    uint32_t resolve_lanes; // ... lanes with queued candidates before the exact tests run
     uint32_t shade_lanes;   // ... lanes with a finished walk that trigger a shading-only stage
     uint32_t reshade_lanes; // ... second shading round of a service stage from this many lanes
     uint32_t lanes_per_pixel; // pixel-owner kernel: 1, or 2..64 (power of two) lanes

@@ -30,6 +30,7 @@ struct SceneRecords {
     // hierarchy (always in global memory), see csrc/bvh_build.hpp
     const F4 *bvh_nodes;
     const uint32_t *bvh_order;
+    const F4 *bvh_leaf_geom;
     const uint32_t *bvh_unbounded;
     uint32_t n_nodes;
     uint32_t n_unbounded;
@@ -205,6 +206,10 @@ PT_HD Hit poisoned_hit(const SceneRecords &rec, V3 o, V3 d) {
 constexpr uint32_t kScreenBlock = 8;
 constexpr uint32_t kScreenQueue = 12; // >= kScreenBlock + 1
 constexpr uint32_t kLeafRef = 0x80000000u; // BVH refs: bit 31 = leaf (csrc/bvh_build.hpp)
+#ifndef PT_LEAF_MAX
+#define PT_LEAF_MAX 4
+#endif
+constexpr uint32_t kLeafSlots = PT_LEAF_MAX; // objects per leaf at most (= bvh_build.hpp's kLeafMax)
 
 struct ScreenQueue {
     uint32_t *slot;   // this lane's entry 0 in LDS
@@ -224,6 +229,32 @@ __device__ __forceinline__ bool screen_keep(const F4 g, V3 o, V3 d) {
     // certainly misses iff (perp2 - r2) - 2^-16 * (dpp + r2) > 0
     const float excess = __builtin_fmaf(dpp + r2, -0x1.0p-16f, perp2 - r2);
     return !(excess > 0.0f);
+}
+
+// One leaf of the hierarchy: its objects' records lie side by side in
+// bvh_leaf_geom / bvh_order (padded), so all kLeafSlots of them are fetched at
+// once -- one memory round trip, where reading order[] and then geom[order[]]
+// object by object took up to eight in a row (half of the stream kernel's wave
+// cycles were spent waiting for memory) -- screened, and the survivors of the
+// first `count` appended to the lane's candidate queue.
+__device__ __forceinline__ void visit_leaf(const SceneRecords &rec, uint32_t leaf_ref, V3 o, V3 d,
+                                           uint32_t min_index, uint32_t *&wr, uint32_t stride) {
+    const uint32_t count = (leaf_ref >> 28) & 7u;
+    const uint32_t at = leaf_ref & 0x0FFFFFFFu;
+    F4 g[kLeafSlots];
+    uint32_t id[kLeafSlots];
+#pragma unroll
+    for (uint32_t k = 0; k < kLeafSlots; ++k) {
+        g[k] = rec.bvh_leaf_geom[at + k];
+        id[k] = rec.bvh_order[at + k];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kLeafSlots; ++k) {
+        if (k < count && id[k] >= min_index && screen_keep(g[k], o, d)) {
+            *wr = id[k];
+            wr += stride;
+        }
+    }
 }
 
 __device__ __forceinline__ Hit closest_hit_screened(const SceneRecords &rec,
@@ -308,6 +339,35 @@ __device__ __forceinline__ Hit closest_hit_screened(const SceneRecords &rec,
 #ifndef PT_BVH_RESOLVE_AT
 #define PT_BVH_RESOLVE_AT 1u /* measured: 1 beats 0, 3 and 8 (C5 57 vs 58, 60, 62 ms) */
 #endif
+
+// One inner node: both children's boxes (binary16 on the device, rounded outward
+// at upload) and refs, from two 16-byte records.
+struct NodeBoxes {
+    F4 l_lo, l_hi, r_lo, r_hi; // .w unused
+    uint32_t l_ref, r_ref;
+};
+__device__ __forceinline__ float half_lo(uint32_t u) {
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)(u & 0xFFFFu));
+}
+__device__ __forceinline__ float half_hi(uint32_t u) {
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)(u >> 16));
+}
+__device__ __forceinline__ NodeBoxes load_node(const SceneRecords &rec, uint32_t node) {
+    const F4 a = rec.bvh_nodes[2u * node + 0u];
+    const F4 b = rec.bvh_nodes[2u * node + 1u];
+    const uint32_t a0 = __builtin_bit_cast(uint32_t, a.x), a1 = __builtin_bit_cast(uint32_t, a.y),
+                   a2 = __builtin_bit_cast(uint32_t, a.z);
+    const uint32_t b0 = __builtin_bit_cast(uint32_t, b.x), b1 = __builtin_bit_cast(uint32_t, b.y),
+                   b2 = __builtin_bit_cast(uint32_t, b.z);
+    NodeBoxes n;
+    n.l_lo = F4{half_lo(a0), half_hi(a0), half_lo(a1), 0.0f};
+    n.l_hi = F4{half_hi(a1), half_lo(a2), half_hi(a2), 0.0f};
+    n.r_lo = F4{half_lo(b0), half_hi(b0), half_lo(b1), 0.0f};
+    n.r_hi = F4{half_hi(b1), half_lo(b2), half_hi(b2), 0.0f};
+    n.l_ref = __builtin_bit_cast(uint32_t, a.w);
+    n.r_ref = __builtin_bit_cast(uint32_t, b.w);
+    return n;
+}
 
 struct UnorderedBest {
     float best;     // smallest positive distance so far
@@ -441,15 +501,11 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
             while (__any(cur != kDone && !(cur & kLeafRef))) {
                 PT_BVH_COUNT(0, cur != kDone && !(cur & kLeafRef));
                 if (cur != kDone && !(cur & kLeafRef)) {
-                    const F4 l_lo = rec.bvh_nodes[4u * cur + 0u];
-                    const F4 l_hi = rec.bvh_nodes[4u * cur + 1u];
-                    const F4 r_lo = rec.bvh_nodes[4u * cur + 2u];
-                    const F4 r_hi = rec.bvh_nodes[4u * cur + 3u];
+                    const NodeBoxes nb = load_node(rec, cur);
                     float l_enter, r_enter;
-                    const bool go_l = crosses(l_lo, l_hi, l_enter);
-                    const bool go_r = crosses(r_lo, r_hi, r_enter);
-                    const uint32_t l_ref = __builtin_bit_cast(uint32_t, l_lo.w);
-                    const uint32_t r_ref = __builtin_bit_cast(uint32_t, r_lo.w);
+                    const bool go_l = crosses(nb.l_lo, nb.l_hi, l_enter);
+                    const bool go_r = crosses(nb.r_lo, nb.r_hi, r_enter);
+                    const uint32_t l_ref = nb.l_ref, r_ref = nb.r_ref;
                     if (go_l & go_r) {
                         const bool r_first = r_enter < l_enter;
                         *sp = r_first ? l_ref : r_ref; // the farther child waits
@@ -467,15 +523,7 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
             }
             PT_BVH_COUNT(2, cur != kDone);
             if (cur != kDone) { // a leaf
-                const uint32_t count = (cur >> 28) & 7u;
-                const uint32_t at = cur & 0x0FFFFFFFu;
-                for (uint32_t k = 0; k < count; ++k) {
-                    const uint32_t idx = rec.bvh_order[at + k];
-                    if (idx >= min_index && screen_keep(rec.geom[idx], o, d)) {
-                        *wr = idx;
-                        wr += q.stride;
-                    }
-                }
+                visit_leaf(rec, cur, o, d, min_index, wr, q.stride);
                 if (sp != q.stack) {
                     sp -= q.stride;
                     cur = *sp;
@@ -582,6 +630,22 @@ __device__ __forceinline__ bool bvh_walk_idle(const ScreenQueue q, const BvhWalk
     return w.cur == kBvhDone && w.wr == q.slot;
 }
 
+#ifdef PT_STAMPS
+#define PT_QSTAMP(var)                                                         \
+    unsigned long long var;                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");  \
+    __builtin_amdgcn_sched_barrier(0)
+#define PT_QSTAMP_ADD(slot, later, earlier)                                    \
+    do {                                                                       \
+        if (prof != nullptr)                                                   \
+            reinterpret_cast<unsigned long long *>(prof)[slot] += (later) - (earlier); \
+    } while (0)
+#else
+#define PT_QSTAMP(var)
+#define PT_QSTAMP_ADD(slot, later, earlier)
+#endif
+
 // One quantum for the lanes with `mine`: up to `inner_budget` inner-node
 // steps (the loop also ends when no lane stands on an inner node), then one
 // leaf for the lanes that stand on one, then exact tests of the queued
@@ -589,13 +653,13 @@ __device__ __forceinline__ bool bvh_walk_idle(const ScreenQueue q, const BvhWalk
 __device__ __forceinline__ void bvh_walk_quantum(const SceneRecords &rec,
                                                  const ScreenQueue q, V3 o, V3 d,
                                                  bool mine, uint32_t inner_budget,
+                                                 uint32_t leaf_lanes, uint32_t resolve_lanes,
                                                  BvhWalk &w, uint32_t *prof = nullptr) {
     (void)prof;
-    // Leaves are visited once 16 lanes stand on one (or no lane can take an
-    // inner step), exact tests run once 4 lanes have candidates (or one has 8,
-    // or nothing else can move): measured on configuration 5, worth 3 % over
-    // "as soon as any lane can".
-    constexpr uint32_t leaf_lanes = 16u, resolve_lanes = 4u;
+    // Leaves are visited once `leaf_lanes` (16) lanes stand on one (or no lane
+    // can take an inner step), exact tests run once `resolve_lanes` (4) lanes
+    // have candidates (or one has 8, or nothing else can move): measured on
+    // configuration 5, worth 3 % over "as soon as any lane can".
     auto crosses = [&](const F4 lo, const F4 hi, float &enter) {
         const float x0 = (lo.x - o.x) * w.inv.x, x1 = (hi.x - o.x) * w.inv.x;
         const float y0 = (lo.y - o.y) * w.inv.y, y1 = (hi.y - o.y) * w.inv.y;
@@ -616,21 +680,18 @@ __device__ __forceinline__ void bvh_walk_quantum(const SceneRecords &rec,
             w.cur = kBvhDone;
         }
     };
+    PT_QSTAMP(q_begin);
     for (uint32_t step = 0; step < inner_budget; ++step) {
         const bool inner = mine && w.cur != kBvhDone && !(w.cur & kLeafRef);
         if (!__any(inner))
             break;
         PT_BVH_COUNT(0, inner);
         if (inner) {
-            const F4 l_lo = rec.bvh_nodes[4u * w.cur + 0u];
-            const F4 l_hi = rec.bvh_nodes[4u * w.cur + 1u];
-            const F4 r_lo = rec.bvh_nodes[4u * w.cur + 2u];
-            const F4 r_hi = rec.bvh_nodes[4u * w.cur + 3u];
+            const NodeBoxes nb = load_node(rec, w.cur);
             float l_enter, r_enter;
-            const bool go_l = crosses(l_lo, l_hi, l_enter);
-            const bool go_r = crosses(r_lo, r_hi, r_enter);
-            const uint32_t l_ref = __builtin_bit_cast(uint32_t, l_lo.w);
-            const uint32_t r_ref = __builtin_bit_cast(uint32_t, r_lo.w);
+            const bool go_l = crosses(nb.l_lo, nb.l_hi, l_enter);
+            const bool go_r = crosses(nb.r_lo, nb.r_hi, r_enter);
+            const uint32_t l_ref = nb.l_ref, r_ref = nb.r_ref;
             if (go_l & go_r) {
                 const bool r_first = r_enter < l_enter;
                 *w.sp = r_first ? l_ref : r_ref; // the farther child waits
@@ -643,6 +704,8 @@ __device__ __forceinline__ void bvh_walk_quantum(const SceneRecords &rec,
             }
         }
     }
+    PT_QSTAMP(q_inner);
+    PT_QSTAMP_ADD(0, q_inner, q_begin);
     const bool at_leaf = mine && w.cur != kBvhDone && (w.cur & kLeafRef);
     const unsigned long long leaf_mask = __ballot(at_leaf);
     const bool do_leaves = (uint32_t)__popcll(leaf_mask) >= leaf_lanes ||
@@ -651,17 +714,11 @@ __device__ __forceinline__ void bvh_walk_quantum(const SceneRecords &rec,
         PT_BVH_COUNT(2, at_leaf);
     }
     if (do_leaves && at_leaf) {
-        const uint32_t count = (w.cur >> 28) & 7u;
-        const uint32_t at = w.cur & 0x0FFFFFFFu;
-        for (uint32_t k = 0; k < count; ++k) {
-            const uint32_t idx = rec.bvh_order[at + k];
-            if (idx >= w.min_index && screen_keep(rec.geom[idx], o, d)) {
-                *w.wr = idx;
-                w.wr += q.stride;
-            }
-        }
+        visit_leaf(rec, w.cur, o, d, w.min_index, w.wr, q.stride);
         pop();
     }
+    PT_QSTAMP(q_leaf);
+    PT_QSTAMP_ADD(1, q_leaf, q_inner);
     const bool pending = mine && w.wr != q.slot;
     const bool pressing = mine && (w.wr > q.slot + 7u * q.stride);
     const bool can_step = mine && w.cur != kBvhDone;
@@ -677,6 +734,8 @@ __device__ __forceinline__ void bvh_walk_quantum(const SceneRecords &rec,
         if (mine)
             w.wr = q.slot;
     }
+    PT_QSTAMP(q_exact);
+    PT_QSTAMP_ADD(2, q_exact, q_leaf);
 }
 
 // For a lane whose walk is idle: either restarts it as the second walk (the

@@ -412,6 +412,7 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
         static_cast<const unsigned char *>(h->blob) + (bytes ? bytes : 16));
     h->desc.bvh_nodes = nullptr;
     h->desc.bvh_order = nullptr;
+    h->desc.bvh_leaf_geom = nullptr;
     h->desc.bvh_unbounded = nullptr;
     h->desc.n_nodes = 0;
     h->desc.n_unbounded = 0;
@@ -440,17 +441,28 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
             }
         }
         const pt::BvhHost bvh = pt::build_bvh(geom, n_obj, corners.data());
-        const size_t node_bytes = bvh.nodes.size() * sizeof(pt::F4);
-        const size_t order_bytes = bvh.order.size() * sizeof(uint32_t);
+        // A leaf visit fetches kLeafMax slots of `order` and of the geometry
+        // copied into leaf order, whatever the leaf's count (one memory round
+        // trip instead of two per object): both arrays are padded accordingly.
+        const size_t slots = bvh.order.size() + pt::kLeafMax;
+        std::vector<pt::F4> leaf_geom(slots, pt::F4{0.0f, 0.0f, 0.0f, 0.0f});
+        for (size_t j = 0; j < bvh.order.size(); ++j)
+            leaf_geom[j] = geom[bvh.order[j]];
+        const std::vector<pt::F4> packed_nodes = pt::pack_nodes_half(bvh.nodes);
+        const size_t node_bytes = packed_nodes.size() * sizeof(pt::F4);
+        const size_t leaf_bytes = slots * sizeof(pt::F4);
+        const size_t order_bytes = slots * sizeof(uint32_t);
         const size_t unb_bytes = bvh.unbounded.size() * sizeof(uint32_t);
-        const size_t total = node_bytes + order_bytes + unb_bytes + 16;
+        const size_t total = node_bytes + leaf_bytes + order_bytes + unb_bytes + 16;
         std::vector<unsigned char> packed(total, 0);
         if (node_bytes) // (memcpy's arguments may not be null, even for 0 bytes)
-            std::memcpy(packed.data(), bvh.nodes.data(), node_bytes);
-        if (order_bytes)
-            std::memcpy(packed.data() + node_bytes, bvh.order.data(), order_bytes);
+            std::memcpy(packed.data(), packed_nodes.data(), node_bytes);
+        std::memcpy(packed.data() + node_bytes, leaf_geom.data(), leaf_bytes);
+        if (!bvh.order.empty())
+            std::memcpy(packed.data() + node_bytes + leaf_bytes, bvh.order.data(),
+                        bvh.order.size() * sizeof(uint32_t));
         if (unb_bytes)
-            std::memcpy(packed.data() + node_bytes + order_bytes, bvh.unbounded.data(), unb_bytes);
+            std::memcpy(packed.data() + node_bytes + leaf_bytes + order_bytes, bvh.unbounded.data(), unb_bytes);
         hipError_t be = hipMalloc(&h->bvh_blob, total);
         if (be == hipSuccess)
             be = hipMemcpy(h->bvh_blob, packed.data(), total, hipMemcpyHostToDevice);
@@ -463,8 +475,9 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
         }
         const unsigned char *b0 = static_cast<const unsigned char *>(h->bvh_blob);
         h->desc.bvh_nodes = reinterpret_cast<const pt::F4 *>(b0);
-        h->desc.bvh_order = reinterpret_cast<const uint32_t *>(b0 + node_bytes);
-        h->desc.bvh_unbounded = reinterpret_cast<const uint32_t *>(b0 + node_bytes + order_bytes);
+        h->desc.bvh_leaf_geom = reinterpret_cast<const pt::F4 *>(b0 + node_bytes);
+        h->desc.bvh_order = reinterpret_cast<const uint32_t *>(b0 + node_bytes + leaf_bytes);
+        h->desc.bvh_unbounded = reinterpret_cast<const uint32_t *>(b0 + node_bytes + leaf_bytes + order_bytes);
         h->desc.n_nodes = (uint32_t)(bvh.nodes.size() / 4);
         h->desc.n_unbounded = (uint32_t)bvh.unbounded.size();
         h->desc.bvh_root = bvh.root;
@@ -557,6 +570,13 @@ constexpr uint32_t kStreamReshadeLanes = 4;
 // Between full services, 16 lanes with a finished walk get a shading-only stage
 // (finished walks are most of what waits; C5, 32 spp: 17.6 -> 16.7 ms)
 constexpr uint32_t kStreamShadeLanes = 16;
+// (PTGPU_LEAF_LANES / PTGPU_RESOLVE_LANES: tuning knobs of the same kind)
+uint32_t stream_knob(const char *name, uint32_t fallback) {
+    uint32_t v = fallback;
+    if (env_u32(name, &v) && v >= 1 && v <= 64)
+        return v;
+    return fallback;
+}
 uint32_t stream_walk_budget() {
     static const uint32_t budget = [] {
         uint32_t v = 4u;
@@ -1094,6 +1114,10 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
             q.stream_walks = 1u;
             q.settle_lanes = p->settle_lanes ? p->settle_lanes : kStreamServiceLanes;
             q.walk_budget = stream_walk_budget();
+            static const uint32_t leaf_lanes = stream_knob("PTGPU_LEAF_LANES", 16u);
+            static const uint32_t resolve_lanes = stream_knob("PTGPU_RESOLVE_LANES", 4u);
+            q.leaf_lanes = leaf_lanes;
+            q.resolve_lanes = resolve_lanes;
             q.reshade_lanes = kStreamReshadeLanes;
             q.shade_lanes = kStreamShadeLanes;
         }

@@ -108,7 +108,60 @@ void check_tree(const std::vector<F4> &geom, const char *what) {
 
 } // namespace
 
+// The device copy of the nodes holds binary16 boxes rounded OUTWARD
+// (pack_nodes_half): a lower corner may only move down, an upper corner only
+// up, by one binary16 step at most, and the refs survive untouched.
+void check_half_rounding() {
+    std::mt19937 rng(99);
+    std::uniform_real_distribution<float> mant(1.0f, 2.0f);
+    std::vector<float> xs = {0.0f, -0.0f, 1.0f, -1.0f, 65504.0f, 65505.0f, -65519.9f, 65520.0f, 1e6f, -1e30f,
+                             6.103515625e-05f, 6.1e-05f, 5.9604645e-08f, 3e-08f, -3e-08f, 1e-20f, 2047.9f,
+                             std::numeric_limits<float>::infinity(), -std::numeric_limits<float>::infinity(),
+                             std::numeric_limits<float>::denorm_min(), 0.1f, -0.1f, 1000.0f, -1001.8f};
+    for (int e = -30; e <= 20; ++e)
+        for (int k = 0; k < 200; ++k)
+            xs.push_back(std::ldexp(mant(rng), e) * ((k & 1) ? -1.0f : 1.0f));
+    for (float x : xs) {
+        const float down = pt::half_value(pt::half_directed(x, false));
+        const float up = pt::half_value(pt::half_directed(x, true));
+        CHECK(down <= x && x <= up);
+        if (std::fabs(x) <= 65504.0f) { // tight: one binary16 step (2^-10 relative, 2^-24 absolute)
+            const double step = std::max(std::ldexp(std::fabs((double)x), -10), std::ldexp(1.0, -24));
+            CHECK((double)x - down <= step && (double)up - x <= step);
+            if (down == x || up == x)
+                CHECK(down == up || (down < x) != (up > x) || down == up);
+        }
+    }
+    CHECK(pt::half_value(pt::half_directed(1.0f, false)) == 1.0f);
+    CHECK(pt::half_value(pt::half_directed(1.0f, true)) == 1.0f);
+    CHECK(std::isinf(pt::half_value(pt::half_directed(70000.0f, true))));
+    CHECK(pt::half_value(pt::half_directed(70000.0f, false)) == 65504.0f);
+    CHECK(pt::half_value(pt::half_directed(-70000.0f, true)) == -65504.0f);
+    // a packed tree: every packed child box contains the float one, refs equal
+    std::uniform_real_distribution<float> pos(-2000.0f, 2000.0f), rad(0.05f, 30.0f);
+    std::vector<F4> g;
+    for (int i = 0; i < 5000; ++i) {
+        const float r = rad(rng);
+        g.push_back(F4{pos(rng), pos(rng), pos(rng), r * r});
+    }
+    g.push_back(F4{0.0f, -100000.0f, 0.0f, 1e10f}); // a box beyond the binary16 range
+    const pt::BvhHost bvh = pt::build_bvh(g.data(), (uint32_t)g.size());
+    const std::vector<F4> packed = pt::pack_nodes_half(bvh.nodes);
+    CHECK(packed.size() * 2 == bvh.nodes.size());
+    auto lo16 = [](float f) { return pt::half_value((uint16_t)(as_u32(f) & 0xFFFFu)); };
+    auto hi16 = [](float f) { return pt::half_value((uint16_t)(as_u32(f) >> 16)); };
+    for (size_t n = 0; n + 3 < bvh.nodes.size(); n += 4)
+        for (int child = 0; child < 2; ++child) {
+            const F4 &lo = bvh.nodes[n + 2 * child], &hi = bvh.nodes[n + 2 * child + 1];
+            const F4 &p = packed[n / 2 + child];
+            CHECK(as_u32(p.w) == as_u32(lo.w));
+            CHECK(lo16(p.x) <= lo.x && hi16(p.x) <= lo.y && lo16(p.y) <= lo.z);
+            CHECK(hi16(p.y) >= hi.x && lo16(p.z) >= hi.y && hi16(p.z) >= hi.z);
+        }
+}
+
 int main() {
+    check_half_rounding();
     std::mt19937 rng(12345);
     std::uniform_real_distribution<float> pos(-50.0f, 50.0f), rad(0.05f, 2.0f);
     const float inf = std::numeric_limits<float>::infinity();

@@ -21,6 +21,7 @@ with pt.HostScene(c['scene']) as s, pt.DeviceScene(s) as d:
         fn(out, 1)
         d.render(img.data_ptr(), w, h, p, st); torch.cuda.synchronize()
         fn(out, 0)
-        walk, shade, settle, total, refill = [float(out[i]) for i in range(5)]
-        print(f"{name:22s} walk {walk/total:.3f}  shade {shade/total:.3f}  settle {settle/total:.3f}  "
+        walk, shade, settle, total, refill, q_inner, q_leaf, q_exact = [float(out[i]) for i in range(8)]
+        print(f"{name:22s} walk {walk/total:.3f} (inner steps {q_inner/total:.3f}, leaf visits {q_leaf/total:.3f}, "
+              f"exact tests {q_exact/total:.3f})  shade {shade/total:.3f}  settle {settle/total:.3f}  "
               f"refill {refill/total:.3f}  other {1-(walk+shade+settle+refill)/total:.3f}")
