@@ -151,6 +151,12 @@ PT_HD Hit closest_hit(const SceneRecords &rec, V3 o, V3 d) {
     Hit h;
     h.distance = -1.0f;
     h.object = -1;
+    // (Tried in round 2 and not kept: fetching four records per s_load_dwordx16
+    // so that a wave waits for scalar memory once per four objects instead of
+    // twice per object -- configuration 2 stayed at 62.6 ms: the other seven
+    // waves of the SIMD cover those waits, the VALU issue slots are the limit.
+    // Fetching record i + 1 during the test of record i cannot work at all: a
+    // scalar load cannot be waited for individually.)
     for (uint32_t i = 0; i < rec.n_obj; ++i)
         test_object(rec, o, d, i, rec.geom[i], h);
     return h;

@@ -2,6 +2,8 @@
 # tools/pmc_passes.sh <tag> -- <program and args...>
 # Counter passes of one command on the GPU box (rocprofv3 --pmc, one pass per
 # counter group, kernel trace only), summed per kernel into gpurun_out/<tag>_pmc.txt.
+# (SQ / SQC / GRBM counters only: a pass with the TA_* counters aborted inside
+# rocprofv3 on this image and then sat silent until the run was killed.)
 tag=$1; shift; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/pmc_$tag
@@ -10,9 +12,7 @@ cd "$root" && export TMPDIR=/tmp
 groups=(
  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM"
  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAVES"
- "TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
- "TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TA_TCP_STATE_READ_sum"
- "GRBM_GUI_ACTIVE SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_WAIT_INST_LDS"
+ "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
 )
 i=0
 for g in "${groups[@]}"; do
