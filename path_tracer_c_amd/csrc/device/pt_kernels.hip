@@ -559,7 +559,10 @@ __global__ void __launch_bounds__(1024)
 // (five waves per SIMD: 96 VGPRs; the kernel wants ~100 and is measurably
 // slower at the four waves that would give it)
 template <bool kLds>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8)))
+#ifndef PT_STREAM_WAVES
+#define PT_STREAM_WAVES 5
+#endif
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PT_STREAM_WAVES, 8)))
     pt_streamkernel(const LaunchArgs a, const F4 *__restrict__ scene_geom,
                     const F4 *__restrict__ scene_tri,
                     const F4 *__restrict__ scene_mat,
@@ -1093,6 +1096,19 @@ hipError_t launch_sum(const LaunchArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL(pt_sum_kernel, dim3(grid), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
+
+#if defined(PT_FARREJECT_COUNT) && !defined(PT_FAST_MATH)
+extern "C" int ptgpu_debug_farreject(unsigned long long out[4], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_farreject), sizeof(unsigned long long) * 4) != hipSuccess)
+        return -1;
+    if (reset) {
+        unsigned long long zero[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_farreject), zero, sizeof zero) != hipSuccess)
+            return -1;
+    }
+    return 0;
+}
+#endif
 
 #if defined(PT_STAMPS) && !defined(PT_FAST_MATH)
 extern "C" int ptgpu_debug_stamps(unsigned long long out[8], int reset) {

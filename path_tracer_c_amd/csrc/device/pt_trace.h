@@ -122,6 +122,15 @@ struct Hit {
     int object;     // index into the scene's object array, -1 on a miss
 };
 
+// Diagnostic build only (make EXTRA_HIPFLAGS=-DPT_FARREJECT_COUNT): how often
+// could a WAVE skip the sqrt + divide half of a sphere test because every lane's
+// root is already known to lie beyond its best hit?  The
+// predicate here is the idealised one (no safety margins), so the count is an
+// upper bound on what a conservative far-reject could skip.  tools/farreject_count.py.
+#ifdef PT_FARREJECT_COUNT
+__device__ unsigned long long g_farreject[4]; // wave tests with some dscr >= 0 | of those, all lanes far | lane tests | far lanes
+#endif
+
 // One object against the ray, then the accept rule of src/ray.c:25,45: keep a
 // candidate unless (dist >= closest && closest > 0).
 PT_HD void test_object(const SceneRecords &rec, V3 o, V3 d, uint32_t i,
@@ -130,6 +139,29 @@ PT_HD void test_object(const SceneRecords &rec, V3 o, V3 d, uint32_t i,
     bool found;
     if (!is_triangle_record(g)) {
         float t1 = 0.0f, t2 = 0.0f;
+#if defined(PT_FARREJECT_COUNT) && defined(__HIP_DEVICE_COMPILE__) && !defined(PT_FAST_MATH)
+        {
+            const V3 dp = xyz(g) - o;
+            const float ddp = dot(d, dp), dpp = dot(dp, dp);
+            const V3 perp = dp - d * ddp;
+            const float dscr = g.w - dot(perp, perp);
+            const bool has = dscr >= 0.0f;
+            const float best = h.distance, gap = ddp - best, cc = dpp - g.w;
+            // chosen root >= best?  outside: ddp - s >= best; inside: ddp + s >= best;
+            // behind (outside, ddp < 0): not found at all
+            const bool far = has && best > 0.0f &&
+                             (cc > 0.0f ? (ddp < 0.0f || (gap >= 0.0f && gap * gap >= dscr))
+                                        : (gap >= 0.0f || dscr >= gap * gap));
+            const unsigned long long has_mask = __ballot(has), far_mask = __ballot(far);
+            if (has_mask != 0ull && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(true)) - 1)) {
+                atomicAdd(&g_farreject[0], 1ull);
+                if (far_mask == has_mask)
+                    atomicAdd(&g_farreject[1], 1ull);
+                atomicAdd(&g_farreject[2], (unsigned long long)__popcll(has_mask));
+                atomicAdd(&g_farreject[3], (unsigned long long)__popcll(far_mask));
+            }
+        }
+#endif
         found = ray_sphere(o, d, xyz(g), g.w, t1, t2);
         dist = (t1 > 0.0f) ? t1 : t2; // src/ray.c:24
     } else {
@@ -210,7 +242,10 @@ PT_HD Hit poisoned_hit(const SceneRecords &rec, V3 o, V3 d) {
 //            queues that are dense across the wave instead of once per object
 //            per wave.
 constexpr uint32_t kScreenBlock = 8;
-constexpr uint32_t kScreenQueue = 12; // >= kScreenBlock + 1
+#ifndef PT_SCREEN_QUEUE
+#define PT_SCREEN_QUEUE 12
+#endif
+constexpr uint32_t kScreenQueue = PT_SCREEN_QUEUE; // >= kScreenBlock + 1
 constexpr uint32_t kLeafRef = 0x80000000u; // BVH refs: bit 31 = leaf (csrc/bvh_build.hpp)
 #ifndef PT_LEAF_MAX
 #define PT_LEAF_MAX 4
@@ -726,7 +761,7 @@ __device__ __forceinline__ void bvh_walk_quantum(const SceneRecords &rec,
     PT_QSTAMP(q_leaf);
     PT_QSTAMP_ADD(1, q_leaf, q_inner);
     const bool pending = mine && w.wr != q.slot;
-    const bool pressing = mine && (w.wr > q.slot + 7u * q.stride);
+    const bool pressing = mine && (w.wr > q.slot + (kScreenQueue - 5u) * q.stride); // + a leaf of 4 still fits
     const bool can_step = mine && w.cur != kBvhDone;
     if (__any(pressing) || (uint32_t)__popcll(__ballot(pending)) >= resolve_lanes ||
         (__any(pending) && !__any(can_step))) {

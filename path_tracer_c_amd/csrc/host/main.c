@@ -14,6 +14,12 @@
  * PTGPU_DEVICES=n spreads the rows over n GPUs; PTGPU_FRAMES=n renders the
  * frame n times and reports the last.
  *
+ * PTGPU_MULTI=n renders through ptgpu_multi_* (include/ptgpu.h): n devices,
+ * each its row tiles, ONE grouped RCCL send/recv of the shards to device 0,
+ * the frame assembled in HBM there and downloaded once.  With fewer than n
+ * GPUs in the machine the ordinals repeat and the shards travel by peer copies
+ * instead (PTGPU_MULTI_PEER_COPY): the same code but for the collective.
+ *
  * PTGPU_PROGRESSIVE=k switches to the explicit API (include/ptgpu.h): the
  * frame is accumulated k samples at a time into a float accumulator in HBM
  * and out.bmp is rewritten after every pass -- the windowless stand-in for
@@ -183,6 +189,45 @@ cleanup:
     return status;
 }
 
+static int multi_device(scene *world, size_t width, size_t height, char *path, uint32_t n) {
+    ptgpu_params p;
+    ptgpu_params_from_env(&p);
+    int have = ptgpu_device_count();
+    if (have < 1 || n < 1 || n > 64) {
+        fprintf(stderr, "PTGPU_MULTI: %s\n", have < 1 ? ptgpu_last_error() : "1..64 devices");
+        return 1;
+    }
+    int devices[64];
+    for (uint32_t i = 0; i < n; i++)
+        devices[i] = (int)(i % (uint32_t)have);
+    const uint32_t flags = ((uint32_t)have >= n && n >= 2) ? 0u : PTGPU_MULTI_PEER_COPY;
+    const size_t bytes = 3 * width * height;
+    ptgpu_multi *m = NULL;
+    void *d_frame = NULL;
+    uint8_t *frame = malloc(bytes);
+    int status = 1;
+    int rc = ptgpu_set_device(devices[0]);
+    if (rc == PTGPU_OK) rc = ptgpu_multi_create(devices, (int)n, flags, &m);
+    if (rc == PTGPU_OK) rc = ptgpu_multi_upload(m, world);
+    if (rc == PTGPU_OK) rc = ptgpu_device_alloc(bytes, &d_frame);
+    double t0 = seconds_now();
+    if (rc == PTGPU_OK) rc = ptgpu_multi_render(m, d_frame, width, height, &p, 0);
+    double t1 = seconds_now();
+    if (rc == PTGPU_OK && frame != NULL) rc = ptgpu_device_download(frame, d_frame, bytes);
+    if (rc != PTGPU_OK || frame == NULL) {
+        fprintf(stderr, "multi-device render failed: %s\n", ptgpu_last_error());
+    } else {
+        write_bitmap(path, (unsigned int)width, (unsigned int)height, frame, true);
+        printf("%zux%zu over %u devices (%s): %.3f ms -> %s\n", width, height, n,
+               ptgpu_multi_transport(m), (t1 - t0) * 1e3, path);
+        status = 0;
+    }
+    ptgpu_device_free(d_frame);
+    ptgpu_multi_destroy(m);
+    free(frame);
+    return status;
+}
+
 int main(int argc, char **argv) {
     int config = argc > 1 ? atoi(argv[1]) : 0;
     size_t width = argc > 2 ? (size_t)atol(argv[2]) : WIDTH;
@@ -195,6 +240,12 @@ int main(int argc, char **argv) {
         return 1;
     }
 
+    uint32_t multi = env_number("PTGPU_MULTI", 0);
+    if (multi > 0) {
+        int status = multi_device(&world, width, height, path, multi);
+        scene_destroy(&world);
+        return status;
+    }
     uint32_t per_pass = env_number("PTGPU_PROGRESSIVE", 0);
     if (per_pass > 0) {
         int status = progressive(&world, width, height, path, per_pass);

@@ -1666,3 +1666,19 @@ def test_progressive_driver_refuses_a_snapshot_of_another_render(gpu, tmp_path):
     acc.write_bytes(b"not a snapshot")
     r = run(dict(base, PTGPU_RESUME=str(acc)))
     assert r.returncode == 0 and "not a snapshot" in r.stderr and "12/12 spp" in r.stdout
+
+
+def test_host_driver_multi_device_mode_writes_the_same_picture(gpu, tmp_path):
+    """bin/ptrender with PTGPU_MULTI=n: a plain-C host using ptgpu_multi_* -- the
+    frame assembled in HBM on device 0, downloaded once (on this box: the one
+    GPU repeated, shards by peer copy)."""
+    exe = Path(__file__).resolve().parent.parent / "bin" / "ptrender"
+    w, h = 131, 77
+    out = tmp_path / "m.bmp"
+    env = dict(os.environ, PTGPU_SPP="6", PTGPU_BOUNCES="8", PTGPU_SEED="4", PTGPU_MULTI="4")
+    run = subprocess.run([str(exe), "2", str(w), str(h), str(out)], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert run.returncode == 0 and "over 4 devices" in run.stdout, run.stdout + run.stderr
+    with gpu.HostScene(2) as s:
+        ref = gpu.render_frame(s, w, h, spp=6, max_bounces=8, seed=4)
+    assert np.array_equal(_bmp_pixels(out, w, h), ref)
