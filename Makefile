@@ -25,7 +25,7 @@ CFLAGS   := -std=gnu2x -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude
 # second time into namespace pt_fast with contraction on and the approximate
 # sqrt / rcp / rsq instructions as they come (csrc/device/pt_vec.h).
 FASTFLAGS := $(filter-out -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt,$(HIPFLAGS)) \
-             -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -DPT_FAST_MATH -DPT_NS=pt_fast $(EXTRA_FASTFLAGS)
+             -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -DPT_FAST_MATH -DPT_NS=pt_fast -DPT_MEGA_WAVES=8 $(EXTRA_FASTFLAGS)
 
 HOST_OBJS := $(BUILD)/scene.o $(BUILD)/vector.o $(BUILD)/bitmap.o $(BUILD)/scenes.o
 HIP_OBJS  := $(BUILD)/pt_kernels.o $(BUILD)/pt_kernels_fast.o $(BUILD)/pt_glsl.o $(BUILD)/ptgpu_abi.o

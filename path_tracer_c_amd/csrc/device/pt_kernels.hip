@@ -323,8 +323,18 @@ __device__ __forceinline__ void count_block(Counters *c, uint4 *tally, uint32_t 
 // ---------------------------------------------------------------------------
 // Kernel 1: one work-item per pixel (pixel-owner mode).
 // ---------------------------------------------------------------------------
+// Waves per SIMD the register allocator must leave room for.  The exact build's
+// path kernels fit 60 VGPRs unprompted (8 waves); the tolerance build's want 71
+// (7 waves) and are held to 64: no spill, 43.9 -> 42.4 ms on configuration 2.
+// The branching variants and the screened / BVH pixel-owner variants keep
+// their registers (they would spill).
+#ifndef PT_MEGA_WAVES
+#define PT_MEGA_WAVES 1
+#endif
 template <bool kLds, bool kTree, int kScan>
-__global__ void __launch_bounds__(1024) pt_megakernel(const LaunchArgs a) {
+__global__ void __launch_bounds__(1024)
+    __attribute__((amdgpu_waves_per_eu((kTree || kScan != 0) ? 1 : PT_MEGA_WAVES, 8)))
+    pt_megakernel(const LaunchArgs a) {
     extern __shared__ uint4 lds_dyn[]; // 16-byte aligned base
     const uint32_t tid = threadIdx.x;
     const uint32_t nthreads = blockDim.x;
