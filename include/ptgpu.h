@@ -311,6 +311,12 @@ int ptgpu_render_frame_multi(const scene *host_scene, uint8_t *frame,
  *   ptgpu_render_device_multi   create + upload + render + destroy in one call
  */
 #define PTGPU_MULTI_PEER_COPY 0x1u
+#define PTGPU_MULTI_RCCL_LOOPBACK 0x2u /* test aid: RCCL, but the ordinals may repeat (even
+                                         all the same).  The communicator spans the distinct
+                                         devices; shards that share devices[0] travel by
+                                         ncclSend / ncclRecv to self.  Runs the library calls
+                                         -- dlopen, ncclCommInitAll, the grouped exchange,
+                                         the stream ordering -- on a box with one GPU */
 typedef struct ptgpu_multi ptgpu_multi;
 int ptgpu_multi_create(const int *devices, int n_devices, uint32_t flags, ptgpu_multi **out);
 int ptgpu_multi_upload(ptgpu_multi *m, const scene *host_scene);

@@ -44,6 +44,7 @@ FLAG_WHOLE_WALKS = 0x800
 FLAG_FAST_MATH = 0x1000
 FLAG_GLSL_SEMANTICS = 0x2000
 MULTI_PEER_COPY = 0x1
+MULTI_RCCL_LOOPBACK = 0x2
 
 MAX_BOUNCES_PATH = 62
 MAX_BOUNCES_TREE = 14

@@ -1646,6 +1646,12 @@ struct ptgpu_multi {
     std::vector<DeviceBuffer> shards;    // on device r (r >= 1)
     DeviceBuffer stage;                  // on devices[0]: every shard, back to back
     bool use_rccl = false;
+    // RCCL ranks = the DISTINCT devices of the list, in order of first
+    // appearance (rank 0 = devices[0]).  With all ordinals different (the
+    // normal case) shard r is rank r; PTGPU_MULTI_RCCL_LOOPBACK lets ordinals
+    // repeat, several shards then share a rank and its first shard's stream.
+    std::vector<int> rank_of;            // per shard
+    std::vector<int> lead_shard;         // per rank: its first shard (whose stream carries the rank's sends)
     std::mutex lock;
 };
 
@@ -1683,8 +1689,10 @@ int ptgpu_multi_create(const int *devices, int n_devices, uint32_t flags, ptgpu_
     *out = nullptr;
     if (devices == nullptr || n_devices <= 0 || n_devices > (int)pt::kMaxShards)
         return fail(PTGPU_ERR_INVALID, "bad device list");
-    if (flags & ~PTGPU_MULTI_PEER_COPY)
+    if (flags & ~(PTGPU_MULTI_PEER_COPY | PTGPU_MULTI_RCCL_LOOPBACK))
         return fail(PTGPU_ERR_INVALID, "unknown flag");
+    if ((flags & PTGPU_MULTI_PEER_COPY) && (flags & PTGPU_MULTI_RCCL_LOOPBACK))
+        return fail(PTGPU_ERR_INVALID, "one transport at a time");
     const int have = ptgpu_device_count();
     if (have < 0)
         return have;
@@ -1692,14 +1700,17 @@ int ptgpu_multi_create(const int *devices, int n_devices, uint32_t flags, ptgpu_
         if (devices[i] < 0 || devices[i] >= have)
             return fail(PTGPU_ERR_INVALID, "device ordinal out of range");
     const bool peer_copy = (flags & PTGPU_MULTI_PEER_COPY) != 0;
+    const bool loopback = (flags & PTGPU_MULTI_RCCL_LOOPBACK) != 0;
     if (!peer_copy) {
         // a communicator spans distinct devices, and a gather needs a peer
         std::vector<int> sorted(devices, devices + n_devices);
         std::sort(sorted.begin(), sorted.end());
         const bool distinct = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
-        if (n_devices < 2 || !distinct)
+        if (!loopback && (n_devices < 2 || !distinct))
             return fail(PTGPU_ERR_LIMIT, "the RCCL gather needs at least two distinct devices "
                                          "(PTGPU_MULTI_PEER_COPY rehearses on fewer)");
+        if (loopback && n_devices < 2)
+            return fail(PTGPU_ERR_LIMIT, "at least two shards, or nothing travels");
         if (!rccl().why.empty())
             return fail(PTGPU_ERR_NO_DEVICE, rccl().why);
     }
@@ -1712,6 +1723,18 @@ int ptgpu_multi_create(const int *devices, int n_devices, uint32_t flags, ptgpu_
     m->scenes.assign(n_devices, nullptr);
     m->shards.assign(n_devices, DeviceBuffer());
     m->use_rccl = !peer_copy;
+    std::vector<int> rank_devices;
+    m->rank_of.assign(n_devices, 0);
+    for (int r = 0; r < n_devices; ++r) {
+        size_t k = 0;
+        while (k < rank_devices.size() && rank_devices[k] != devices[r])
+            ++k;
+        if (k == rank_devices.size()) {
+            rank_devices.push_back(devices[r]);
+            m->lead_shard.push_back(r);
+        }
+        m->rank_of[r] = (int)k;
+    }
     int home = 0;
     hipError_t e = hipGetDevice(&home);
     for (int r = 0; r < n_devices && e == hipSuccess; ++r) {
@@ -1723,8 +1746,9 @@ int ptgpu_multi_create(const int *devices, int n_devices, uint32_t flags, ptgpu_
     }
     int rc = e == hipSuccess ? PTGPU_OK : fail_hip(e, "multi-device setup");
     if (rc == PTGPU_OK && m->use_rccl) {
-        m->comms.assign(n_devices, nullptr);
-        const ncclResult_t ne = rccl().CommInitAll(m->comms.data(), n_devices, devices);
+        m->comms.assign(rank_devices.size(), nullptr);
+        const ncclResult_t ne = rccl().CommInitAll(m->comms.data(), (int)rank_devices.size(),
+                                                   rank_devices.data());
         if (ne != ncclSuccess)
             rc = fail_nccl(ne, "ncclCommInitAll");
     }
@@ -1835,7 +1859,7 @@ int ptgpu_multi_render(ptgpu_multi *m, uint8_t *d_frame, size_t framew, size_t f
         q.tile_stride = G;
         q.flags |= PTGPU_FLAG_COMPACT_ROWS;
         rc = render_common(m->scenes[r], dst, nullptr, framew, frameh, &q, m->streams[r], true);
-        if (rc == PTGPU_OK && !m->use_rccl && r != 0)
+        if (rc == PTGPU_OK && r != 0)
             PT_TRY_HIP(hipEventRecord(m->rendered[r], m->streams[r]));
     }
     // ---- ONE exchange: shards 1..G-1 -> devices[0] ---------------------------------
@@ -1846,9 +1870,20 @@ int ptgpu_multi_render(ptgpu_multi *m, uint8_t *d_frame, size_t framew, size_t f
             if (shard_rows[r] == 0)
                 continue;
             const size_t bytes = row_bytes * shard_rows[r];
-            ne = R.Send(m->shards[r].ptr, bytes, ncclUint8, 0, m->comms[r], m->streams[r]);
+            // (all ordinals different: rank r sends on its own stream.  Loopback:
+            // the rank's lead stream sends, once this shard has been rendered)
+            const int rank = m->rank_of[r];
+            const hipStream_t send_stream = m->streams[m->lead_shard[rank]];
+            if (m->lead_shard[rank] != (int)r) {
+                const hipError_t we = hipStreamWaitEvent(send_stream, m->rendered[r], 0);
+                if (we != hipSuccess) {
+                    (void)R.GroupEnd();
+                    return fail_hip(we, "hipStreamWaitEvent");
+                }
+            }
+            ne = R.Send(m->shards[r].ptr, bytes, ncclUint8, 0, m->comms[rank], send_stream);
             if (ne == ncclSuccess)
-                ne = R.Recv(m->stage.ptr + sa.shard_offset[r], bytes, ncclUint8, (int)r,
+                ne = R.Recv(m->stage.ptr + sa.shard_offset[r], bytes, ncclUint8, rank,
                             m->comms[0], m->streams[0]);
         }
         const ncclResult_t ge = R.GroupEnd();

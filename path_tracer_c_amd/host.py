@@ -248,12 +248,12 @@ class MultiDevice:
     devices[0] by one grouped ncclSend/ncclRecv (or, with peer_copy=True, by
     peer copies: a rehearsal that also runs with repeated ordinals)."""
 
-    def __init__(self, devices, peer_copy=False):
+    def __init__(self, devices, peer_copy=False, rccl_loopback=False):
+        from ._abi import MULTI_PEER_COPY, MULTI_RCCL_LOOPBACK
         self.handle = C.c_void_p()
         arr = (C.c_int * len(devices))(*devices)
-        check(lib().ptgpu_multi_create(arr, len(devices),
-                                       _abi_flags_peer_copy() if peer_copy else 0,
-                                       C.byref(self.handle)))
+        flags = (MULTI_PEER_COPY if peer_copy else 0) | (MULTI_RCCL_LOOPBACK if rccl_loopback else 0)
+        check(lib().ptgpu_multi_create(arr, len(devices), flags, C.byref(self.handle)))
 
     @property
     def transport(self) -> str:
@@ -277,11 +277,6 @@ class MultiDevice:
 
     def __exit__(self, *exc):
         self.close()
-
-
-def _abi_flags_peer_copy():
-    from ._abi import MULTI_PEER_COPY
-    return MULTI_PEER_COPY
 
 
 def resolve(d_accum_ptr: int, d_frame_ptr: int, npixels: int, stream: int = 0):

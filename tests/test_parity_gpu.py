@@ -1682,3 +1682,16 @@ def test_host_driver_multi_device_mode_writes_the_same_picture(gpu, tmp_path):
     with gpu.HostScene(2) as s:
         ref = gpu.render_frame(s, w, h, spp=6, max_bounces=8, seed=4)
     assert np.array_equal(_bmp_pixels(out, w, h), ref)
+
+
+def test_multi_device_rccl_calls_on_one_gpu_by_loopback(gpu):
+    """The RCCL plumbing of ptgpu_multi_* on the one GPU of the box: librccl
+    dlopen()ed, ncclCommInitAll over the single distinct device, the shards
+    of three "devices" (all ordinal 0) moved by grouped ncclSend / ncclRecv to
+    self, stream ordering, scatter -- frame equal to the single-launch frame.
+    In a child process under a timeout (tools/multi_rccl_check.py)."""
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    run = subprocess.run([sys.executable, str(root / "tools" / "multi_rccl_check.py"), "--loopback", "3"],
+                         capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "loopback" in run.stdout, run.stdout + run.stderr

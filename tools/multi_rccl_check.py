@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
-"""ptgpu_multi_render over RCCL against the single-device frame, on a machine
-with >= 2 GPUs in one process.  Exit 0 = equal, 77 = fewer than two GPUs.
+"""ptgpu_multi_render over RCCL against the single-device frame.  Exit 0 = equal.
 
-    python tools/multi_rccl_check.py [n_devices]
+    python tools/multi_rccl_check.py [n_devices]     >= 2 GPUs in one process (77 = fewer)
+    python tools/multi_rccl_check.py --loopback n    ONE GPU: n shards on device 0, the
+                                                     communicator has one rank and every
+                                                     shard travels by ncclSend/ncclRecv to
+                                                     self (PTGPU_MULTI_RCCL_LOOPBACK): the
+                                                     library calls and the stream ordering
+                                                     on real hardware, without a second GPU
 
 Run by tests/test_parity_gpu.py in a child process with a timeout, so that a
 collective that ever hung could not hang the test suite."""
@@ -20,12 +25,16 @@ import path_tracer_c_amd as pt  # noqa: E402
 def main():
     L = pt.lib()
     have = L.ptgpu_device_count()
-    want = int(sys.argv[1]) if len(sys.argv) > 1 else min(have, 8)
-    if have < 2 or want < 2:
-        print(f"{have} GPU(s): the RCCL gather needs two")
-        return 77
-    devices = list(range(min(want, have)))
-    w, h = 1920, 1080
+    loopback = len(sys.argv) > 1 and sys.argv[1] == "--loopback"
+    if loopback:
+        devices = [0] * (int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+    else:
+        want = int(sys.argv[1]) if len(sys.argv) > 1 else min(have, 8)
+        if have < 2 or want < 2:
+            print(f"{have} GPU(s): the RCCL gather needs two")
+            return 77
+        devices = list(range(min(want, have)))
+    w, h = (1920, 1080) if not loopback else (641, 360)
     p = pt.make_params(spp=32, max_bounces=8, seed=3)
     pt._abi.check(L.ptgpu_set_device(0))
     d_full, d_multi = C.c_void_p(), C.c_void_p()
@@ -38,7 +47,7 @@ def main():
         pt._abi.check(L.ptgpu_device_synchronize())
         pt._abi.check(L.ptgpu_device_download(full.ctypes.data_as(C.c_void_p), d_full, full.nbytes))
         t0 = time.perf_counter()
-        with pt.host.MultiDevice(devices) as md:
+        with pt.host.MultiDevice(devices, rccl_loopback=loopback) as md:
             t1 = time.perf_counter()
             assert md.transport == "rccl"
             md.upload(s)
@@ -52,7 +61,7 @@ def main():
                 if not np.array_equal(multi, full):
                     print(f"tile_rows {tile}: {int((multi != full).sum())} bytes differ")
                     return 1
-                print(f"{len(devices)} devices, tile_rows {tile or 8}: frame equal to the single-device "
+                print(f"{len(devices)} {'shards on one device (loopback)' if loopback else 'devices'}, tile_rows {tile or 8}: frame equal to the single-device "
                       f"frame; {1e3 * (t3 - t2):.2f} ms per frame (communicators {1e3 * (t1 - t0):.0f} ms)")
     return 0
 
