@@ -2270,7 +2270,8 @@ struct PoolTask {
 // function's contract, src/renderer.c:92-116), so work cannot be put off; it
 // can be done AHEAD: when calls walk the rows in order, the next miss renders
 // twice as many rows as the last one (1, 2, 4, ... up to the rest of the
-// frame) into a host-side cache, and the calls that follow are a memcpy.  A
+// frame; downwards or upwards) into a host-side cache, and the calls that
+// follow are a memcpy.  A
 // row is a pure function of (scene content, settings, frame size, row), which
 // is the cache's key -- a caller that edits its scene between calls gets fresh
 // rows.  A 1080-row frame costs 11 launches instead of 1080; once a frame has
@@ -2326,35 +2327,42 @@ void legacy_one_row(const scene *world, uint8_t *frame, size_t framew, size_t fr
                           c.frameh == frameh && same_settings(c.params, now);
     if (same_key && y >= c.row_begin && y < c.row_begin + c.num_rows) {
         std::memcpy(frame + row_bytes * y, c.rows.data() + row_bytes * (y - c.row_begin), row_bytes);
-        if (y + 1 == frameh)
-            c.walked_to_the_end = true;
         return;
     }
     // a miss: how far ahead?  Twice the last batch when this row continues the
     // walk (just past the cached rows); the whole frame when the last frame of
     // this key was walked to its end and this one starts at the top
+    // (the walk may also go UP the frame: the reference's own pool hands out
+    // the newest task first, src/threadpool.c:28, i.e. the bottom row first)
     uint32_t ahead = 1;
-    if (same_key && y == c.row_begin + c.num_rows)
-        ahead = c.batch < (1u << 30) ? 2u * c.batch : c.batch;
-    else if (same_key && c.walked_to_the_end && y == 0)
-        ahead = (uint32_t)frameh;
-    if ((uint64_t)y + ahead > frameh)
-        ahead = (uint32_t)(frameh - y);
+    uint32_t begin = y;
+    const uint32_t twice = c.batch < (1u << 30) ? 2u * c.batch : c.batch;
+    if (same_key && y == c.row_begin + c.num_rows) { // continues downwards
+        ahead = twice;
+    } else if (same_key && y + 1u == c.row_begin) { // continues upwards
+        ahead = twice < y + 1u ? twice : y + 1u;
+        begin = y + 1u - ahead;
+    } else if (same_key && c.walked_to_the_end && (y == 0 || y + 1u == frameh)) {
+        ahead = (uint32_t)frameh; // the last frame was walked through: fetch this one whole
+        begin = 0;
+    }
+    if ((uint64_t)begin + ahead > frameh)
+        ahead = (uint32_t)(frameh - begin);
     c.valid = false;
     c.world = world;
     c.hash = h;
     c.framew = framew;
     c.frameh = frameh;
     c.params = now;
-    c.row_begin = y;
+    c.row_begin = begin;
     c.num_rows = ahead;
     c.batch = ahead;
     c.walked_to_the_end = false;
     c.rows.resize(row_bytes * ahead);
-    legacy_render_rows(world, c.rows.data(), framew, frameh, y, ahead, /*dest_compact=*/true);
+    legacy_render_rows(world, c.rows.data(), framew, frameh, begin, ahead, /*dest_compact=*/true);
     c.valid = true;
-    std::memcpy(frame + row_bytes * y, c.rows.data(), row_bytes);
-    if (y + 1 == frameh)
+    std::memcpy(frame + row_bytes * y, c.rows.data() + row_bytes * (y - begin), row_bytes);
+    if (begin == 0 || begin + ahead == frameh)
         c.walked_to_the_end = true;
 }
 

@@ -1589,7 +1589,13 @@ def test_direct_render_task_calls_read_ahead_and_stay_exact(gpu, oracle, monkeyp
         n_second = gpu.host.read_stats().launches
         assert np.array_equal(first, ref) and np.array_equal(second, ref)
         assert n_first <= 7 and n_second == 1, (n_first, n_second)
-        # bottom-up, and a scattered order: every call still returns its own row
+        # bottom-up (the order the reference's pool pops its tasks in): read-ahead upwards too
+        monkeypatch.setenv("PTGPU_SEED", "13")
+        ref13, _ = oracle.render_rows(s, w, h, spp=6, max_bounces=4, seed=13)
+        gpu.host.reset_stats()
+        assert np.array_equal(_direct_rows(gpu, s, w, h, range(h - 1, -1, -1)), ref13)
+        assert gpu.host.read_stats().launches <= 7
+        monkeypatch.setenv("PTGPU_SEED", "11")
         assert np.array_equal(_direct_rows(gpu, s, w, h, range(h - 1, -1, -1)), ref)
         order = list(np.random.default_rng(3).permutation(h))
         assert np.array_equal(_direct_rows(gpu, s, w, h, order), ref)
@@ -1695,3 +1701,20 @@ def test_multi_device_rccl_calls_on_one_gpu_by_loopback(gpu):
     run = subprocess.run([sys.executable, str(root / "tools" / "multi_rccl_check.py"), "--loopback", "3"],
                          capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and "loopback" in run.stdout, run.stdout + run.stderr
+
+
+def test_the_references_own_threadpool_drives_render_task(gpu):
+    """oracle/_ref/libref_host.so = the reference's threadpool.c, unmodified: its
+    8 worker threads call this library's render_task row by row (rows arrive
+    out of order and concurrently: the read-ahead cache and the locks under
+    real contention) and the frame equals ptgpu_render_frame's.  In a child
+    process (tools/ref_pool_check.py), which leaves without the reference's
+    threadpool_destroy -- that hangs with more than one worker."""
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    if not (root / "oracle" / "_ref" / "libref_host.so").exists():
+        pytest.skip("oracle/_ref is not built (no /root/reference at build time)")
+    run = subprocess.run([sys.executable, str(root / "tools" / "ref_pool_check.py")],
+                         capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert run.stdout.count("frame equal to ptgpu_render_frame: True") == 2, run.stdout
