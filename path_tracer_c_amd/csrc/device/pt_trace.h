@@ -761,7 +761,7 @@ __device__ __forceinline__ void bvh_walk_quantum(const SceneRecords &rec,
     PT_QSTAMP(q_leaf);
     PT_QSTAMP_ADD(1, q_leaf, q_inner);
     const bool pending = mine && w.wr != q.slot;
-    const bool pressing = mine && (w.wr > q.slot + (kScreenQueue - 5u) * q.stride); // + a leaf of 4 still fits
+    const bool pressing = mine && (w.wr > q.slot + (kScreenQueue - kLeafSlots - 1u) * q.stride); // + one more leaf still fits
     const bool can_step = mine && w.cur != kBvhDone;
     if (__any(pressing) || (uint32_t)__popcll(__ballot(pending)) >= resolve_lanes ||
         (__any(pending) && !__any(can_step))) {
