@@ -468,7 +468,10 @@ def main():
                 "kernel": "pt_trace_kernel", "rays": n_rays, "ms": ms, "value": n_rays / ms / 1e3,
                 "unit": "Mray/s", "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
                                                "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                                               "bytes_per_ray": 64},
+                                               "bytes_per_ray": 64,
+                                               "frac_of_measured_copy_rate": gbs / 6290.0,
+                                               "note": "MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s "
+                                                       "measured for a float4 copy"},
                 "note": "ptgpu_trace_rays_device, eye rays of a 4096x4096 image; not part of `value`"}
             del dirs, orgs, hits, ix, dx, dy
         if world == 1 and not args.no_cpu_baseline:
