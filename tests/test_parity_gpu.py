@@ -1718,3 +1718,22 @@ def test_the_references_own_threadpool_drives_render_task(gpu):
                          capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout + run.stderr
     assert run.stdout.count("frame equal to ptgpu_render_frame: True") == 2, run.stdout
+
+
+def test_glsl_semantics_randomised_scenes_match_the_shader_oracle(gpu, oracle):
+    """The hostile random scenes of the fuzz test above (any scale, zero / huge /
+    negative radii, slivers, camera inside spheres, every transparency class
+    including branching ones, roughness above 1) through the shader renderer's
+    rules: bit-equal to oracle/pt_glsl.c."""
+    rng = np.random.default_rng(int(os.environ.get("PT_FUZZ_SEED", "2025")) + 77)
+    trials = int(os.environ.get("PT_FUZZ_TRIALS", "40"))
+    for trial in range(trials):
+        with _random_scene(gpu, rng, branching=bool(trial % 2)) as s:
+            w, h = int(rng.integers(8, 60)), int(rng.integers(5, 36))
+            spp = int(rng.integers(1, 4))
+            b = int(rng.integers(0, 7))
+            seed = int(rng.integers(0, 2**31))
+            got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=seed,
+                                   flags=gpu._abi.FLAG_GLSL_SEMANTICS)
+            ref = oracle.glsl_render_rows(s, w, h, spp=spp, max_bounces=b, seed=seed)[0]
+            assert np.array_equal(got, ref), (trial, w, h, spp, b, seed, s.counts())
