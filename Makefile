@@ -22,10 +22,15 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-s
 CFLAGS   := -std=gnu2x -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude
 
 # The tolerance mode (PTGPU_FLAG_FAST_MATH): the same device sources compiled a
-# second time into namespace pt_fast with contraction on and the approximate
-# sqrt / rcp / rsq instructions as they come (csrc/device/pt_vec.h).
-FASTFLAGS := $(filter-out -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt,$(HIPFLAGS)) \
-             -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -DPT_FAST_MATH -DPT_NS=pt_fast -DPT_MEGA_WAVES=8 $(EXTRA_FASTFLAGS)
+# second time into namespace pt_fast with explicit fused multiply-adds and the
+# approximate sqrt / rcp / rsq instructions as they come (csrc/device/pt_vec.h).
+# Same compiler flags as the exact build: -ffp-contract stays OFF and the `/` and
+# sqrtf() operators stay IEEE.  What makes the mode cheaper is written out in
+# the source (pt_vec.h, pt_trace.h): explicit fused multiply-adds and the
+# v_sqrt / v_rcp / v_rsq builtins.  Left to the compiler (-ffp-contract=fast,
+# approximate division) the same expression came out differently in different
+# kernels and the mode's frames depended on the schedule.
+FASTFLAGS := $(HIPFLAGS) -DPT_FAST_MATH -DPT_NS=pt_fast -DPT_MEGA_WAVES=8 $(EXTRA_FASTFLAGS)
 
 HOST_OBJS := $(BUILD)/scene.o $(BUILD)/vector.o $(BUILD)/bitmap.o $(BUILD)/scenes.o
 HIP_OBJS  := $(BUILD)/pt_kernels.o $(BUILD)/pt_kernels_fast.o $(BUILD)/pt_glsl.o $(BUILD)/ptgpu_abi.o

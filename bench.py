@@ -424,8 +424,8 @@ def main():
                     "bytes_equal": float((diff == 0).float().mean()),
                     "rmse_8bit_levels": float(diff.float().pow(2).mean().sqrt()),
                     "mean_diff": float(diff.float().mean())},
-                "note": "tolerance build: fused multiply-adds, v_sqrt/v_rcp/v_rsq as they come, "
-                        "17-FLOP discriminant; the default build stays bit-exact"}
+                "note": "tolerance build: fused multiply-adds, v_sqrt/v_rcp/v_rsq as they come; "
+                        "the default build stays bit-exact"}
             local[:h].copy_(exact_frame)
             del exact_frame, diff
         if world == 1 and not progressive:

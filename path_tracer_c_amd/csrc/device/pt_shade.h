@@ -37,7 +37,11 @@ __device__ __forceinline__ V3 rand_unit_sphere(uint32_t &state) {
     float ry = ptgpu_u32_to_unit(state);
     state = ptgpu_xorshift32(state);
     float rz = ptgpu_u32_to_unit(state);
+#if defined(PT_FAST_MATH)
+    V3 cube = madd(V3{rx, ry, rz}, 2.0f, splat(-1.0f));
+#else
     V3 cube = V3{rx, ry, rz} * 2.0f - splat(1.0f);
+#endif
     return normalize(cube);
 }
 
@@ -49,10 +53,19 @@ struct Bounce {
     bool has_child;
 };
 
+// origin of a child ray: point + direction * 0.001 (src/renderer.c:49,66)
+__device__ __forceinline__ V3 ray_origin(V3 point, V3 direction) {
+#if defined(PT_FAST_MATH)
+    return madd(direction, kRayOffset, point);
+#else
+    return point + direction * kRayOffset;
+#endif
+}
+
 __device__ __forceinline__ Bounce reflect_ray(V3 d, V3 n, V3 point) {
     Bounce b;
     b.direction = normalize_dir(reflect(d, n));
-    b.origin = point + b.direction * kRayOffset;
+    b.origin = ray_origin(point, b.direction);
     b.has_child = true;
     return b;
 }
@@ -65,7 +78,7 @@ __device__ __forceinline__ Bounce refract_ray(V3 d, V3 n, V3 point) {
     V3 bent;
     b.has_child = refract(d, rn, eta, bent);
     b.direction = normalize_dir(bent);
-    b.origin = point + b.direction * kRayOffset;
+    b.origin = ray_origin(point, b.direction);
     return b;
 }
 
@@ -78,7 +91,11 @@ __device__ __forceinline__ V3 shade_level(const F4 m0, const F4 m1, V3 child) {
     V3 refl = via_reflection ? child : splat(0.0f);
     V3 trans = via_reflection ? splat(0.0f) : child;
     V3 li = lerp(refl, trans, t);
+#if defined(PT_FAST_MATH)
+    return madd(li, xyz(m0), xyz(m1));
+#else
     return xyz(m1) + li * xyz(m0);
+#endif
 }
 
 // ---------------------------------------------------------------------------

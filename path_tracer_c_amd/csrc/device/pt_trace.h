@@ -51,20 +51,26 @@ PT_HD bool is_triangle_record(const F4 &g) {
 // Returns false when there is no root or both roots are behind the origin.
 PT_HD bool ray_sphere(V3 o, V3 d, V3 c, float r2, float &t1, float &t2) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(PT_FAST_SPHERE)
-    // tolerance mode: the 17-FLOP discriminant b^2 - (|dp|^2 - r^2) without the
-    // remedy term, fused; the roots still as q and c/q (no cancellation: a ray
-    // leaving a radius-1000 wall must not find that wall again), with
-    // v_sqrt_f32 / v_rcp_f32 as they come
-    // (|dp|^2 - r^2 decides on which side of the surface the origin lies, and a
+    // Tolerance mode: the reference's formulation -- remedy term, roots as q and
+    // c/q -- with fused multiply-adds and v_sqrt_f32 / v_rcp_f32 as they come.
+    // (The 17-FLOP discriminant b^2 - (|dp|^2 - r^2) was tried first.  It
+    // cancels: its error is ~1e-7 b^2 whatever the radius, so a zero-radius
+    // sphere 12000 units away "was hit" by a ray passing 4.5 units from it, and
+    // -- the hierarchy rightly never looking there -- frames differed between
+    // scan forms (found by the mode's fuzz test).  The remedy term costs 6
+    // more instructions per sphere and keeps the error ~1e-7 |dp_perp|^2.)
+    //
+    // |dp|^2 - r^2 decides on which side of the surface the origin lies, and a
     // ray leaving a radius-1000 sphere by 0.001 sits within one or two of its
     // rounding steps of zero: the reference's own self-intersection rule lives
     // in the last bits of this value, so it is rounded exactly as the
     // reference rounds it -- otherwise a few per cent of all paths through such
-    // a scene take a different, if equally valid, course)
+    // a scene take a different, if equally valid, course.
     const V3 dp = c - o;
     const float b = dot(d, dp);
     const float cc = dot_seq(dp, dp) - r2;
-    const float disc = __builtin_fmaf(b, b, -cc);
+    const V3 perp = madd(d, -b, dp);
+    const float disc = r2 - dot(perp, perp);
     if (disc < 0.0f)
         return false;
     const float s = __builtin_amdgcn_sqrtf(disc);
@@ -98,22 +104,29 @@ PT_HD bool ray_sphere(V3 o, V3 d, V3 c, float r2, float &t1, float &t2) {
 
 // glms_ray_triangle (Moeller-Trumbore, eps 1e-6, two-sided) with the edges
 // e1 = v1 - v0 and e2 = v2 - v0 taken from the uploaded record.
+// The same arithmetic in BOTH builds: the tolerance build does not cheapen the
+// triangle test.  On a sliver (edges parallel to a part in 10^6) the
+// determinant is rounding noise, and which noise decides hit or miss anywhere
+// along the ray: the hierarchy's triangle boxes are sized for THIS sequence of
+// roundings (csrc/bvh_build.hpp), and with fused cross products the linear
+// scans "hit" slivers where the hierarchy had rightly not looked (found by the
+// mode's fuzz test: frames differed between scan forms).
 PT_HD bool ray_triangle(V3 o, V3 d, V3 v0, V3 e1, V3 e2, float &dist) {
     const float eps = 0.000001f;
-    V3 p = cross(d, e2);
-    float det = dot(e1, p);
+    V3 p = cross_seq(d, e2);
+    float det = dot_seq(e1, p);
     if (det > -eps && det < eps)
         return false;
-    float inv_det = rcp_rn(det);
+    float inv_det = rcp_ieee(det);
     V3 t = o - v0;
-    float u = inv_det * dot(t, p);
+    float u = inv_det * dot_seq(t, p);
     if (u < 0.0f || u > 1.0f)
         return false;
-    V3 q = cross(t, e1);
-    float v = inv_det * dot(d, q);
+    V3 q = cross_seq(t, e1);
+    float v = inv_det * dot_seq(d, q);
     if (v < 0.0f || u + v > 1.0f)
         return false;
-    dist = inv_det * dot(e2, q);
+    dist = inv_det * dot_seq(e2, q);
     return dist > eps;
 }
 
@@ -820,7 +833,11 @@ PT_HD Surface surface_at(const SceneRecords &rec, V3 o, V3 d, Hit h) {
     const F4 g = rec.geom[h.object];
     const uint32_t meta = rec.meta[h.object];
     s.material = meta & kMetaMaterialMask;
+#if defined(PT_FAST_MATH)
+    s.point = madd(d, h.distance, o);
+#else
     s.point = d * h.distance + o;
+#endif
     if (!is_triangle_record(g)) {
         s.normal = normalize(s.point - xyz(g));
     } else {

@@ -24,10 +24,15 @@
 
 // The device code is compiled twice (Makefile): as namespace `pt` under the
 // bit-exact contract described above, and -- with -DPT_FAST_MATH
-// -DPT_NS=pt_fast -ffp-contract=fast -- as namespace `pt_fast`, the opt-in
-// tolerance mode behind PTGPU_FLAG_FAST_MATH (include/ptgpu.h): fused
-// multiply-adds, v_sqrt_f32 / v_rcp_f32 / v_rsq_f32 without their correction
-// steps, the 17-FLOP discriminant.  Same algorithm, same random stream, same
+// -DPT_NS=pt_fast -- as namespace `pt_fast`, the opt-in tolerance mode behind
+// PTGPU_FLAG_FAST_MATH (include/ptgpu.h): fused multiply-adds, v_sqrt_f32 /
+// v_rcp_f32 / v_rsq_f32 without their correction steps.  The fusions and approximations are WRITTEN OUT (madd / dot /
+// cross / the builtins below) and the build keeps the exact build's compiler
+// flags (-ffp-contract=off, IEEE `/` and sqrtf): left to the compiler
+// (-ffp-contract=fast, approximate division) the same expression came out
+// differently in different kernels -- a sample queue frame differed from the
+// pixel-owner frame of the same scene (found by the mode's fuzz test) -- this
+// way every kernel of the mode does the same arithmetic, as in the exact build.  Same algorithm, same random stream, same
 // launch plumbing; results agree with the exact build to the tolerance
 // tests/test_parity_gpu.py states, not to the bit.  The layout types
 // (pt_layout.h, pt_launch.h) live in `pt` for both.
@@ -64,22 +69,48 @@ PT_HD V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
 PT_HD V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
 PT_HD V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
 
-// x*x' + y*y' + z*z', summed left to right (glms_vec3_dot).
-PT_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-
-// The same sum with every product and sum rounded on its own, also in the
-// tolerance build, where -ffp-contract=fast lets the backend fuse any multiply
-// with any add (no pragma stops that; an empty asm the products pass through
-// does, at no instruction).
-PT_HD float dot_seq(V3 a, V3 b) {
-    float px = a.x * b.x, py = a.y * b.y, pz = a.z * b.z;
-#if defined(__HIP_DEVICE_COMPILE__) && defined(PT_FAST_MATH)
-    asm("" : "+v"(px), "+v"(py), "+v"(pz));
+// a * b + c: two roundings in the exact build (as the reference's separate
+// operations round), one fused multiply-add in the tolerance build.
+PT_HD float mul_add(float a, float b, float c) {
+#if defined(PT_FAST_MATH) && defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmaf(a, b, c);
+#else
+    return a * b + c;
 #endif
-    return px + py + pz;
+}
+PT_HD V3 madd(V3 a, float s, V3 b) { // a * s + b
+    return V3{mul_add(a.x, s, b.x), mul_add(a.y, s, b.y), mul_add(a.z, s, b.z)};
+}
+PT_HD V3 madd(V3 a, V3 s, V3 b) { // a * s + b, component-wise
+    return V3{mul_add(a.x, s.x, b.x), mul_add(a.y, s.y, b.y), mul_add(a.z, s.z, b.z)};
 }
 
+// x*x' + y*y' + z*z', summed left to right (glms_vec3_dot).
+PT_HD float dot(V3 a, V3 b) {
+#if defined(PT_FAST_MATH) && defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x));
+#else
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+#endif
+}
+
+// The same sum with every product and sum rounded on its own in BOTH builds
+// (the tolerance build needs it in two places: pt_trace.h ray_sphere,
+// normalize_dir below).
+PT_HD float dot_seq(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
 PT_HD V3 cross(V3 a, V3 b) {
+#if defined(PT_FAST_MATH) && defined(__HIP_DEVICE_COMPILE__)
+    return V3{__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
+              __builtin_fmaf(a.x, b.y, -(a.y * b.x))};
+#else
+    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z,
+              a.x * b.y - a.y * b.x};
+#endif
+}
+
+// cross product with every product and difference rounded on its own, in both builds
+PT_HD V3 cross_seq(V3 a, V3 b) {
     return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z,
               a.x * b.y - a.y * b.x};
 }
@@ -126,16 +157,22 @@ PT_HD float sqrt_rn(float x) {
 #endif
 }
 
-PT_HD float rcp_rn(float x) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(PT_FAST_RECIP)
-    return __builtin_amdgcn_rcpf(x); // v_rcp_f32, 1 ulp
-#else
+// correctly rounded 1/x in BOTH builds (the tolerance build needs it where a
+// result must agree with the exact build's: pt_trace.h, ray_triangle)
+PT_HD float rcp_ieee(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t mag = f32_bits(x) & 0x7FFFFFFFu;
     if (__builtin_expect(mag - 0x20800000u <= 0x3E000000u, 1)) // [2^-62, 2^62]
         return rcp_core(x);
 #endif
     return 1.0f / x;
+}
+
+PT_HD float rcp_rn(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PT_FAST_RECIP)
+    return __builtin_amdgcn_rcpf(x); // v_rcp_f32, 1 ulp
+#else
+    return rcp_ieee(x);
 #endif
 }
 
@@ -202,7 +239,13 @@ PT_HD V3 normalize_dir(V3 a) {
 }
 
 // glms_vec3_lerp: from + (to - from) * t, not clamped.
-PT_HD V3 lerp(V3 from, V3 to, float t) { return from + (to - from) * t; }
+PT_HD V3 lerp(V3 from, V3 to, float t) {
+#if defined(PT_FAST_MATH) && defined(__HIP_DEVICE_COMPILE__)
+    return madd(to - from, t, from);
+#else
+    return from + (to - from) * t;
+#endif
+}
 
 // glm_clamp = min(max(v, lo), hi) built from `a > b ? a : b`; NaN -> lo.
 PT_HD float clampf(float v, float lo, float hi) {
@@ -217,20 +260,32 @@ PT_HD V3 clamp01(V3 v) {
 // glms_vec3_reflect: v - n * (2 * dot(v, n)).
 PT_HD V3 reflect(V3 v, V3 n) {
     float twice = 2.0f * dot(v, n);
+#if defined(PT_FAST_MATH) && defined(__HIP_DEVICE_COMPILE__)
+    return madd(n, -twice, v);
+#else
     return v - n * twice;
+#endif
 }
 
 // glms_vec3_refract: false (and a zero vector) on total internal reflection.
 PT_HD bool refract(V3 v, V3 n, float eta, V3 &out) {
     float ndi = dot(n, v);
     float eni = eta * ndi;
+#if defined(PT_FAST_MATH) && defined(__HIP_DEVICE_COMPILE__)
+    float k = __builtin_fmaf(eni, eni, __builtin_fmaf(-eta, eta, 1.0f));
+#else
     float k = 1.0f - eta * eta + eni * eni;
+#endif
     if (k < 0.0f) {
         out = splat(0.0f);
         return false;
     }
     float along = eni + sqrt_rn(k);
+#if defined(PT_FAST_MATH) && defined(__HIP_DEVICE_COMPILE__)
+    out = madd(n, -along, v * eta);
+#else
     out = v * eta - n * along;
+#endif
     return true;
 }
 
