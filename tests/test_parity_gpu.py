@@ -1758,3 +1758,61 @@ def test_fast_math_randomised_scenes_are_the_same_picture_in_every_scan_form(gpu
             for f in forms:
                 got = gpu.render_frame(s, w, h, flags=A.FLAG_FAST_MATH | f, **kw)
                 assert np.array_equal(got, ref), (trial, hex(f), w, h, kw, s.counts())
+
+
+def test_multi_device_gather_randomised(gpu, torch_cuda):
+    """ptgpu_multi_render (peer-copy rehearsal on the one GPU) over random frame
+    sizes, shard counts, tile heights, row sub-ranges and modes, against the
+    single-launch frame."""
+    A = gpu._abi
+    rng = np.random.default_rng(int(os.environ.get("PT_FUZZ_SEED", "2025")) + 5)
+    trials = int(os.environ.get("PT_FUZZ_TRIALS", "40")) // 4 + 2
+    for trial in range(trials):
+        w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+        shards = int(rng.integers(1, 9))
+        tile = int(rng.choice([0, 1, 2, 3, 8, 17]))
+        first = int(rng.integers(0, h))
+        rows = int(rng.integers(1, h - first + 1))
+        flags = int(rng.choice([0, A.FLAG_FAST_MATH, A.FLAG_GLSL_SEMANTICS, A.FLAG_SAMPLE_QUEUE]))
+        kw = dict(spp=int(rng.integers(1, 5)), max_bounces=int(rng.integers(0, 6)), seed=trial, flags=flags)
+        with gpu.HostScene(int(rng.choice([0, 1, 2]))) as s, gpu.DeviceScene(s) as d:
+            full = render_device(gpu, torch_cuda, d, w, h, **kw)
+            with gpu.host.MultiDevice([0] * shards, peer_copy=True) as md:
+                md.upload(s)
+                got = _multi_frame(gpu, torch_cuda, md, w, h, tile, row_begin=first, num_rows=rows, **kw)
+        assert np.array_equal(got[first:first + rows], full[first:first + rows]), (trial, w, h, shards, tile, first, rows, hex(flags))
+        assert not got[:first].any() and not got[first + rows:].any()
+
+
+def test_direct_render_task_randomised_call_orders(gpu, oracle, monkeypatch):
+    """render_task called directly in random orders (runs up, runs down, jumps,
+    repeats), with the scene or the settings changed in between: every call
+    returns its row of the scene as it is at that moment."""
+    rng = np.random.default_rng(int(os.environ.get("PT_FUZZ_SEED", "2025")) + 6)
+    trials = int(os.environ.get("PT_FUZZ_TRIALS", "40")) // 4 + 2
+    monkeypatch.setenv("PTGPU_SPP", "3")
+    monkeypatch.setenv("PTGPU_BOUNCES", "4")
+    for trial in range(trials):
+        w, h = int(rng.integers(4, 50)), int(rng.integers(2, 40))
+        with gpu.HostScene(int(rng.choice([0, 1, 2]))) as s:
+            seed = int(rng.integers(1, 1000))
+            monkeypatch.setenv("PTGPU_SEED", str(seed))
+            ref, _ = oracle.render_rows(s, w, h, spp=3, max_bounces=4, seed=seed)
+            frame = np.zeros((h, w, 3), dtype=np.uint8)
+            want = np.zeros_like(frame)
+            y = int(rng.integers(h))
+            for _ in range(int(rng.integers(h, 4 * h))):
+                move = rng.integers(10)
+                if move < 4:
+                    y = (y + 1) % h
+                elif move < 7:
+                    y = (y - 1) % h
+                elif move < 9:
+                    y = int(rng.integers(h))
+                elif move == 9 and rng.integers(4) == 0:       # edit the scene: later rows are the new scene's
+                    s.c.objects[0].sphere.radius *= 1.05
+                    ref, _ = oracle.render_rows(s, w, h, spp=3, max_bounces=4, seed=seed)
+                _direct_rows(gpu, s, w, h, [y], frame=frame)
+                want[y] = ref[y]
+                assert np.array_equal(frame[y], want[y]), (trial, y)
+            assert np.array_equal(frame, want)
