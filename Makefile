@@ -32,7 +32,7 @@ CFLAGS   := -std=gnu2x -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude
 # kernels and the mode's frames depended on the schedule.
 FASTFLAGS := $(HIPFLAGS) -DPT_FAST_MATH -DPT_NS=pt_fast -DPT_MEGA_WAVES=8 $(EXTRA_FASTFLAGS)
 
-HOST_OBJS := $(BUILD)/scene.o $(BUILD)/vector.o $(BUILD)/bitmap.o $(BUILD)/scenes.o
+HOST_OBJS := $(BUILD)/scene.o $(BUILD)/vector.o $(BUILD)/bitmap.o $(BUILD)/scenes.o $(BUILD)/threadpool.o
 HIP_OBJS  := $(BUILD)/pt_kernels.o $(BUILD)/pt_kernels_fast.o $(BUILD)/pt_glsl.o $(BUILD)/ptgpu_abi.o
 DEV_HDRS  := $(wildcard $(CSRC)/device/*.h) $(wildcard $(CSRC)/*.hpp) $(wildcard include/*.h)
 
@@ -41,7 +41,7 @@ all: $(LIBDIR)/libptgpu.so oracle bin/ptrender
 $(BUILD) $(LIBDIR) bin:
 	mkdir -p $@
 
-$(BUILD)/%.o: $(CSRC)/host/%.c include/path_tracer_api.h include/ptgpu.h | $(BUILD)
+$(BUILD)/%.o: $(CSRC)/host/%.c include/path_tracer_api.h include/ptgpu.h $(CSRC)/host/pool_rows.h | $(BUILD)
 	$(CC) $(CFLAGS) -c $< -o $@
 
 $(BUILD)/pt_kernels.o: $(CSRC)/device/pt_kernels.hip $(DEV_HDRS) | $(BUILD)
@@ -85,9 +85,9 @@ asan-driver: | $(BUILD) bin
 	$(HIPCC) $(filter-out -O3,$(HIPFLAGS)) -O1 -g -c $(CSRC)/device/pt_kernels.hip -o $(BUILD)/asan_kernels.o
 	$(HIPCC) $(filter-out -O3,$(FASTFLAGS)) -O1 -g -c $(CSRC)/device/pt_kernels.hip -o $(BUILD)/asan_kernels_fast.o
 	$(HIPCC) $(filter-out -O3,$(HIPFLAGS)) -O1 -g -c $(CSRC)/device/pt_glsl.hip -o $(BUILD)/asan_glsl.o
-	for f in scene vector bitmap scenes main; do \
+	for f in scene vector bitmap scenes threadpool main; do \
 	  $(CLANG) -std=gnu2x -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -ffp-contract=off -Iinclude \
 	    -c $(CSRC)/host/$$f.c -o $(BUILD)/asan_$$f.o || exit 1; done
 	$(HIPCC) --offload-arch=$(ARCH) -fno-gpu-sanitize -fsanitize=address,undefined -o bin/ptrender_asan \
-	  $(BUILD)/asan_main.o $(BUILD)/asan_scene.o $(BUILD)/asan_vector.o $(BUILD)/asan_bitmap.o $(BUILD)/asan_scenes.o \
+	  $(BUILD)/asan_main.o $(BUILD)/asan_threadpool.o $(BUILD)/asan_scene.o $(BUILD)/asan_vector.o $(BUILD)/asan_bitmap.o $(BUILD)/asan_scenes.o \
 	  $(BUILD)/asan_abi.o $(BUILD)/asan_kernels.o $(BUILD)/asan_kernels_fast.o $(BUILD)/asan_glsl.o -lpthread -lm

@@ -181,7 +181,11 @@ typedef struct {
     bool threads_running;
 } threadpool;
 
+/* Tasks whose function is render_task are queued for the GPU (rendered by
+ * threadpool_wait_for_tasks); any other task is run by one of `num_threads`
+ * worker pthreads at once, newest first, as src/threadpool.c:14-41 does. */
 void threadpool_init(threadpool *pool, size_t num_threads);
+/* Running tasks finish; queued ones are dropped (src/threadpool.c:60-82). */
 void threadpool_destroy(threadpool *pool);
 void threadpool_add_task(threadpool *pool, void (*f)(void *), void *arg);
 /* Returns only when every task added so far has completed. */

@@ -1,10 +1,11 @@
 // ptgpu_abi.hip -- the C-ABI of the MI355X render path (include/ptgpu.h) and
 // the legacy entry points it stands behind (include/path_tracer_api.h:
-// render_task, trace_ray, threadpool_*).
+// render_task, trace_ray; threadpool_* live in host/threadpool.c and call
+// ptgpu_pool_render_rows here).
 //
 // What replaces what (reference file:line):
 //   threadpool_add_task / _wait_for_tasks   src/threadpool.c:84-101
-//     -> rows are queued on the host; wait_for_tasks renders all queued rows
+//     -> host/threadpool.c: rows are queued on the host; wait_for_tasks renders all queued rows
 //        of a frame with one megakernel launch per contiguous row run and
 //        copies them into the caller's frame.  It returns when every queued
 //        task has completed (the intended contract; the reference returns
@@ -36,6 +37,7 @@
 #include "bvh_build.hpp"
 #include "device/pt_launch.h"
 #include "device/pt_vec.h"
+#include "host/pool_rows.h"
 #include "ptgpu.h"
 
 namespace {
@@ -2253,12 +2255,6 @@ void legacy_render_rows(const scene *world, uint8_t *frame, size_t framew,
         die("render");
 }
 
-struct PoolTask {
-    void (*fn)(void *);
-    void *arg;
-    bool is_row;
-    render_args row; // snapshot taken when the task was added
-};
 
 } // namespace
 
@@ -2385,99 +2381,34 @@ ray_hit trace_ray(const vec3s origin, const vec3s direction,
     return hit;
 }
 
-void threadpool_init(threadpool *pool, size_t num_threads) {
-    // No worker threads: the GPU is the pool.  `threads` stays empty.
-    vector_init_with_capacity(&pool->threads, num_threads ? num_threads : 1);
-    vector_init(&pool->tasks);
-    pthread_mutex_init(&pool->tasks_mutex, nullptr);
-    pthread_cond_init(&pool->tasks_available_cond, nullptr);
-    pthread_cond_init(&pool->tasks_exhausted_cond, nullptr);
-    pool->threads_running = true;
-}
-
-void threadpool_add_task(threadpool *pool, void (*f)(void *), void *arg) {
-    PoolTask *t = new PoolTask();
-    t->fn = f;
-    t->arg = arg;
-    t->is_row = (f == reinterpret_cast<void (*)(void *)>(&render_task)) &&
-                arg != nullptr;
-    if (t->is_row)
-        t->row = *static_cast<render_args *>(arg);
-    pthread_mutex_lock(&pool->tasks_mutex);
-    vector_push(&pool->tasks, t);
-    pthread_cond_signal(&pool->tasks_available_cond);
-    pthread_mutex_unlock(&pool->tasks_mutex);
-}
-
-void threadpool_wait_for_tasks(threadpool *pool) {
-    for (;;) {
-        // take everything queued so far
-        std::vector<PoolTask *> batch;
-        pthread_mutex_lock(&pool->tasks_mutex);
-        while (void *t = vector_pop(&pool->tasks))
-            batch.push_back(static_cast<PoolTask *>(t));
-        pthread_mutex_unlock(&pool->tasks_mutex);
-        if (batch.empty())
-            break;
-
-        // foreign tasks run here, on the waiting thread (popped order = LIFO,
-        // as src/vector.c:24-31 pops)
-        std::vector<PoolTask *> rows;
-        for (PoolTask *t : batch) {
-            if (t->is_row)
-                rows.push_back(t);
-            else if (t->fn)
-                t->fn(t->arg);
-        }
-
-        // group row tasks by (frame, size, scene); render each group's rows
-        // as contiguous runs
-        std::stable_sort(rows.begin(), rows.end(),
-                         [](const PoolTask *x, const PoolTask *y) {
-                             const render_args &a = x->row, &b = y->row;
-                             if (a.frame != b.frame) return a.frame < b.frame;
-                             if (a.world != b.world) return a.world < b.world;
-                             if (a.framew != b.framew) return a.framew < b.framew;
-                             if (a.frameh != b.frameh) return a.frameh < b.frameh;
-                             return a.screen_y < b.screen_y;
-                         });
-        size_t i = 0;
-        while (i < rows.size()) {
-            const render_args &head = rows[i]->row;
-            size_t j = i + 1;
-            while (j < rows.size() && rows[j]->row.frame == head.frame &&
-                   rows[j]->row.world == head.world &&
-                   rows[j]->row.framew == head.framew &&
-                   rows[j]->row.frameh == head.frameh &&
-                   (rows[j]->row.screen_y == rows[j - 1]->row.screen_y ||
-                    rows[j]->row.screen_y == rows[j - 1]->row.screen_y + 1))
-                ++j;
-            const int y0 = head.screen_y, y1 = rows[j - 1]->row.screen_y;
-            if (head.frame && head.world && y0 >= 0 &&
-                (size_t)y1 < head.frameh)
-                legacy_render_rows(head.world, head.frame, head.framew,
-                                   head.frameh, (uint32_t)y0,
-                                   (uint32_t)(y1 - y0 + 1));
-            i = j;
-        }
-        for (PoolTask *t : batch)
-            delete t;
+// The pool shim (host/threadpool.c) hands over every row queued so far.
+void ptgpu_pool_render_rows(const render_args *queued, size_t n) {
+    // group by (frame, size, scene); render each group's rows as contiguous runs
+    std::vector<const render_args *> rows(n);
+    for (size_t i = 0; i < n; i++)
+        rows[i] = queued + i;
+    std::stable_sort(rows.begin(), rows.end(), [](const render_args *a, const render_args *b) {
+        if (a->frame != b->frame) return a->frame < b->frame;
+        if (a->world != b->world) return a->world < b->world;
+        if (a->framew != b->framew) return a->framew < b->framew;
+        if (a->frameh != b->frameh) return a->frameh < b->frameh;
+        return a->screen_y < b->screen_y;
+    });
+    size_t i = 0;
+    while (i < rows.size()) {
+        const render_args &head = *rows[i];
+        size_t j = i + 1;
+        while (j < rows.size() && rows[j]->frame == head.frame && rows[j]->world == head.world &&
+               rows[j]->framew == head.framew && rows[j]->frameh == head.frameh &&
+               (rows[j]->screen_y == rows[j - 1]->screen_y ||
+                rows[j]->screen_y == rows[j - 1]->screen_y + 1))
+            ++j;
+        const int y0 = head.screen_y, y1 = rows[j - 1]->screen_y;
+        if (head.frame && head.world && y0 >= 0 && (size_t)y1 < head.frameh)
+            legacy_render_rows(head.world, head.frame, head.framew, head.frameh, (uint32_t)y0,
+                               (uint32_t)(y1 - y0 + 1));
+        i = j;
     }
-    pthread_mutex_lock(&pool->tasks_mutex);
-    pthread_cond_broadcast(&pool->tasks_exhausted_cond);
-    pthread_mutex_unlock(&pool->tasks_mutex);
-}
-
-void threadpool_destroy(threadpool *pool) {
-    pool->threads_running = false;
-    // unexecuted tasks are dropped, as in src/threadpool.c:70-74
-    while (void *t = vector_pop(&pool->tasks))
-        delete static_cast<PoolTask *>(t);
-    vector_free(&pool->threads);
-    vector_free(&pool->tasks);
-    pthread_mutex_destroy(&pool->tasks_mutex);
-    pthread_cond_destroy(&pool->tasks_available_cond);
-    pthread_cond_destroy(&pool->tasks_exhausted_cond);
 }
 
 } // extern "C"

@@ -1058,27 +1058,79 @@ def test_threadpool_two_frames_two_scenes_and_foreign_tasks_in_one_wait(gpu, ora
         r0, _ = oracle.render_rows(s0, 48, 30, spp=4, seed=1)
         assert np.array_equal(f1, r1)
         assert np.array_equal(f0[0::2], r0[0::2]) and not f0[1::2].any()
-        # queued but never waited for: destroy drops them (src/threadpool.c:70-74)
-        before = len(ran)
-        lib.threadpool_add_task(C.byref(pool), C.cast(cb, C.c_void_p), C.c_void_p(7))
+        # rows queued but never waited for: destroy drops them (src/threadpool.c:70-74)
+        f0[:] = 0
+        lib.threadpool_add_task(C.byref(pool), task, C.cast(C.byref(args[len(jobs) - 1]), C.c_void_p))
+        assert pool.tasks.size == 1
         lib.threadpool_destroy(C.byref(pool))
-        assert len(ran) == before
+        assert not f0.any()
 
 
 def test_threadpool_runs_foreign_tasks_and_waits_for_all(gpu):
+    """Ordinary tasks are run by the shim's own worker threads, as the
+    reference's pool runs them: at once (no wait needed), several at a time."""
+    import threading
     A = gpu._abi
     lib = gpu.lib()
     seen = []
     cb = A.TASK_FN(lambda arg: seen.append(arg))
     pool = A.ThreadPool()
     lib.threadpool_init(C.byref(pool), 3)
+    assert pool.threads.size == 3                      # as after the reference's init
     for i in range(1, 6):
         lib.threadpool_add_task(C.byref(pool), C.cast(cb, C.c_void_p), C.c_void_p(i))
-    assert pool.tasks.size == 5                        # queued, public field
     lib.threadpool_wait_for_tasks(C.byref(pool))
     assert sorted(seen) == [1, 2, 3, 4, 5] and pool.tasks.size == 0
     lib.threadpool_wait_for_tasks(C.byref(pool))        # nothing queued: returns at once
+
+    # three tasks that can only finish together: they must be running at the
+    # same time, and before anybody calls wait
+    meet = threading.Barrier(4)
+    together = A.TASK_FN(lambda arg: meet.wait(20))
+    for i in range(3):
+        lib.threadpool_add_task(C.byref(pool), C.cast(together, C.c_void_p), None)
+    meet.wait(20)                                       # the main thread is the fourth party
+    lib.threadpool_wait_for_tasks(C.byref(pool))
     lib.threadpool_destroy(C.byref(pool))
+
+
+def test_threadpool_foreign_tasks_render_beside_the_queued_rows(gpu, oracle, monkeypatch):
+    """A task of the caller's own calls render_task directly (one frame) and
+    queues rows of another frame, while the main thread queues a third: one
+    wait, three correct frames."""
+    monkeypatch.setenv("PTGPU_SPP", "4")
+    A = gpu._abi
+    lib = gpu.lib()
+    task = C.cast(lib.render_task, C.c_void_p)
+    w, h = 40, 24
+    with gpu.HostScene(2) as s:
+        frames = [np.zeros((h, w, 3), dtype=np.uint8) for _ in range(3)]
+        args = [(A.RenderArgs * h)() for _ in range(3)]
+        for f in range(3):
+            for y in range(h):
+                args[f][y] = A.RenderArgs(y, w, h, frames[f].ctypes.data_as(C.POINTER(C.c_uint8)),
+                                          C.pointer(s.c))
+        pool = A.ThreadPool()
+        lib.threadpool_init(C.byref(pool), 4)
+
+        def direct(_):
+            for y in range(h):
+                lib.render_task(C.byref(args[0][y]))
+
+        def queues(_):
+            for y in range(h):
+                lib.threadpool_add_task(C.byref(pool), task, C.cast(C.byref(args[1][y]), C.c_void_p))
+
+        cbs = [A.TASK_FN(direct), A.TASK_FN(queues)]
+        for cb in cbs:
+            lib.threadpool_add_task(C.byref(pool), C.cast(cb, C.c_void_p), None)
+        for y in range(h):
+            lib.threadpool_add_task(C.byref(pool), task, C.cast(C.byref(args[2][y]), C.c_void_p))
+        lib.threadpool_wait_for_tasks(C.byref(pool))
+        lib.threadpool_destroy(C.byref(pool))
+        ref, _ = oracle.render_rows(s, w, h, spp=4, seed=1)
+        for f in range(3):
+            assert np.array_equal(frames[f], ref), f
 
 
 # ---- device-resident API: shards, progressive passes, full-size frames ----------------------

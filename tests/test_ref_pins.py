@@ -192,46 +192,46 @@ def test_one_thread_pool_runs_queued_tasks_last_in_first_out_like_the_reference(
     """The reference's worker pops the NEWEST task (vector_pop,
     src/threadpool.c:28).  With one worker held inside a first task while k more
     are queued, the order is fully determined: k-1 ... 0.  The shim runs
-    foreign (non-render_task) tasks on the waiting thread in the same order.
+    ordinary (non-render_task) tasks the same way, on worker threads of its own
+    (csrc/host/threadpool.c): the same procedure on both pools, same order.
     The reference's threadpool_wait_for_tasks is not called: it waits on a
     condition variable without a predicate (src/threadpool.c:97-101, SURVEY
     3.4) and can miss its wake-up; the test waits on its own event instead."""
     k = 12
-    gate, started, done = threading.Event(), threading.Event(), threading.Event()
-    order = []
 
-    def body(arg):
-        tag = int(arg or 0)
-        if tag == 1000:
-            started.set()
-            gate.wait(10)
-            return
-        order.append(tag - 1)
-        if len(order) == k:
-            done.set()
+    def run_on(init, add, destroy, pool):
+        gate, started, done = threading.Event(), threading.Event(), threading.Event()
+        order = []
 
-    fn = TASK_FN(body)
-    pool = (C.c_ubyte * 192)()
-    ref.threadpool_init(pool, 1)
-    ref.threadpool_add_task(pool, fn, C.c_void_p(1000))
-    assert started.wait(10)
-    for i in range(k):
-        ref.threadpool_add_task(pool, fn, C.c_void_p(i + 1))
-    gate.set()
-    assert done.wait(10)
-    # one worker, now idle in pthread_cond_wait: destroy's single signal
-    # (src/threadpool.c:61) reaches it and the join returns
-    ref.threadpool_destroy(pool)
-    want = list(order)
+        def body(arg):
+            tag = int(arg or 0)
+            if tag == 1000:
+                started.set()
+                gate.wait(10)
+                return
+            order.append(tag - 1)
+            if len(order) == k:
+                done.set()
+
+        fn = TASK_FN(body)
+        init(pool, 1)
+        add(pool, C.cast(fn, C.c_void_p), C.c_void_p(1000))
+        assert started.wait(10)           # the one worker is inside the first task: nothing waits for wait()
+        for i in range(k):
+            add(pool, C.cast(fn, C.c_void_p), C.c_void_p(i + 1))
+        gate.set()
+        assert done.wait(10)
+        # one worker, now idle in pthread_cond_wait: destroy's single signal
+        # (src/threadpool.c:61) reaches it and the join returns
+        destroy(pool)
+        return order
+
+    want = run_on(ref.threadpool_init, ref.threadpool_add_task, ref.threadpool_destroy,
+                  (C.c_ubyte * 192)())
     assert want == list(range(k - 1, -1, -1))
-
-    order.clear()
-    done.clear()
     lib = pt.lib()
     ours = pt._abi.ThreadPool()
-    lib.threadpool_init(C.byref(ours), 1)
-    for i in range(k):
-        lib.threadpool_add_task(C.byref(ours), C.cast(fn, C.c_void_p), C.c_void_p(i + 1))
-    lib.threadpool_wait_for_tasks(C.byref(ours))     # foreign tasks: no GPU needed
-    lib.threadpool_destroy(C.byref(ours))
-    assert order == want
+    got = run_on(lambda p, n: lib.threadpool_init(C.byref(p), n),
+                 lambda p, f, a: lib.threadpool_add_task(C.byref(p), f, a),
+                 lambda p: lib.threadpool_destroy(C.byref(p)), ours)
+    assert got == want

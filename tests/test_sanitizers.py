@@ -42,6 +42,27 @@ def test_oracle_row_pool_under_tsan(tmp_path):
     build_and_run(tmp_path, "selftest_tsan", "thread", {"TSAN_OPTIONS": "halt_on_error=1"})
 
 
+@pytest.mark.parametrize("sanitize", ["thread", "address,undefined"])
+def test_pool_shim_under_sanitizers(tmp_path, sanitize):
+    """csrc/host/threadpool.c (the legacy pool: worker pthreads for ordinary
+    tasks, rows handed to the GPU path at wait) with recording stand-ins for
+    render_task and the GPU call, under TSan and under ASan + UBSan."""
+    exe = tmp_path / "pool_selftest"
+    cmd = ["gcc", "-std=gnu2x", "-O1", "-g", "-fno-omit-frame-pointer", f"-fsanitize={sanitize}",
+           f"-I{ROOT / 'include'}", f"-I{HOST}", str(ROOT / "tests" / "c" / "pool_selftest.c"),
+           str(HOST / "threadpool.c"), str(HOST / "vector.c"), "-o", str(exe), "-lpthread"]
+    built = subprocess.run(cmd, capture_output=True, text=True)
+    if built.returncode != 0 and "sanitize" in built.stderr and "not supported" in built.stderr:
+        pytest.skip(f"-fsanitize={sanitize} not supported by this gcc")
+    assert built.returncode == 0, built.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1",
+                                  UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1"))
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "pool_selftest: ok" in run.stdout
+    assert "runtime error" not in run.stderr and "Sanitizer" not in run.stderr, run.stderr
+
+
 def test_bvh_builder_under_asan_ubsan(tmp_path):
     """csrc/bvh_build.hpp is host C++ inside a HIP translation unit; compiled
     alone with g++ it runs under the sanitizers.  The self-test checks the
