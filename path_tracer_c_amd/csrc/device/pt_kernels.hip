@@ -33,7 +33,8 @@
 //     (src/renderer.c:11-19);
 //   * materials with 0 < transparency < 1 make incident_light a binary tree
 //     (src/renderer.c:45,56,72); scenes that have one run the `kTree`
-//     instantiation, an explicit depth-first walk with a per-lane frame stack;
+//     instantiations of the same kernels: a lane's path follows the reflection,
+//     the transmitted ray is put aside and the unwind resumes there (pt_shade.h);
 //   * RGB8 stores: a wave's 64 pixels are 192 contiguous bytes; lanes 0..47
 //     each assemble one dword with two cross-lane reads and store it.
 //
@@ -367,16 +368,13 @@ __global__ void __launch_bounds__(1024)
     uint32_t rays = 0, scans = 0, iters = 0;
     const uint32_t spp = valid ? a.spp : 0u;
     uint32_t samples_done = owner ? spp : 0u;
-    if (kTree) {
-        run_tree<kScan>(w.rec, a, w.queue, ps.d0, ps.pixel, spp, sky, sum, rays, iters);
-        scans = rays;
-    } else if (k == 1u) {
-        run_paths<kScan>(w.rec, a, w.stack, nthreads, w.queue, ps.d0, ps.pixel,
-                         spp, sky, sum, rays, scans, iters);
+    if (k == 1u) {
+        run_paths<kScan, kTree>(w.rec, a, w.stack, nthreads, w.queue, ps.d0, ps.pixel,
+                                spp, sky, sum, rays, scans, iters);
     } else {
         samples_done = 0u;
-        run_paths_split<kScan>(w.rec, a, w.stack, nthreads, w.queue, ps.d0, ps.pixel,
-                               spp, k, q, sky, sum, rays, scans, iters, samples_done);
+        run_paths_split<kScan, kTree>(w.rec, a, w.stack, nthreads, w.queue, ps.d0, ps.pixel,
+                                      spp, k, q, sky, sum, rays, scans, iters, samples_done);
     }
 
     // ---- write back ------------------------------------------------------------
@@ -385,7 +383,7 @@ __global__ void __launch_bounds__(1024)
             reinterpret_cast<float4 *>(a.accum)[acc_at] =
                 make_float4(sum.x, sum.y, sum.z, had + (float)a.spp);
     } else {
-        if (kTree || k == 1u)
+        if (k == 1u)
             store_rgb8(a.frame, sum, (float)a.spp, ps.out_pixel, owner, tid & 63u);
         else
             store_rgb8_block(a, w.stack, sum, (float)a.spp, ps.out_pixel, owner, tid, nthreads, k,
@@ -480,7 +478,7 @@ constexpr uint32_t kChunkBatchMax = 32; // chunks of 64 tasks reserved per atomi
 // its loop, and without the no-alias guarantee the compiler must assume a
 // store may change the scene, which turns the wave-uniform scalar loads of
 // the object scan (s_load, constant cache) into 64-lane vector loads.
-template <bool kLds, int kScan>
+template <bool kLds, int kScan, bool kTree>
 __global__ void __launch_bounds__(1024)
     pt_samplekernel(const LaunchArgs a, const F4 *__restrict__ scene_geom,
                     const F4 *__restrict__ scene_tri,
@@ -516,6 +514,7 @@ __global__ void __launch_bounds__(1024)
     p.depth = 0;
     p.rng = 1u;
     p.live = p.parked = false;
+    Branches<kTree> br;
     uint32_t rays = 0, iters = 0, done = 0;
 
     for (;;) {
@@ -536,13 +535,14 @@ __global__ void __launch_bounds__(1024)
         ++iters;
         if (p.live) {
             ++rays;
-            advance_path<kScan>(w.rec, a, w.stack, nthreads, w.queue, sky, p);
+            advance_path<kScan, kTree>(w.rec, a, w.stack, nthreads, w.queue, sky, p, br);
         }
 
         // ---- settle parked lanes: unwind, emit the sample, free the lane ----------
+        // (kTree: or go on with a transmitted ray that was put aside)
         if (settle_now(p.live, p.parked, a.settle_lanes)) {
-            if (p.parked) {
-                const V3 sample = unwind_path(w.rec, w.stack, nthreads, p);
+            V3 sample;
+            if (p.parked && settle_path<kTree>(w.rec, a, w.stack, nthreads, sky, p, br, sample)) {
                 out[out_index] = make_float4(sample.x, sample.y, sample.z, 0.0f);
                 p.parked = false;
                 have = false;
@@ -573,10 +573,10 @@ __global__ void __launch_bounds__(1024)
 // ---------------------------------------------------------------------------
 // (five waves per SIMD: 96 VGPRs; the kernel wants ~100 and is measurably
 // slower at the four waves that would give it)
-template <bool kLds>
 #ifndef PT_STREAM_WAVES
 #define PT_STREAM_WAVES 5
 #endif
+template <bool kLds, bool kTree>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PT_STREAM_WAVES, 8)))
     pt_streamkernel(const LaunchArgs a, const F4 *__restrict__ scene_geom,
                     const F4 *__restrict__ scene_tri,
@@ -610,6 +610,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PT_ST
     p.depth = 0;
     p.rng = 1u;
     p.live = p.parked = false;
+    Branches<kTree> br;
     BvhWalk walk;
     walk.inv = splat(0.0f);
     walk.u = UnorderedBest{0.0f, -1, 0.0f, -1};
@@ -653,7 +654,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PT_ST
     // one recursion level of incident_light for the lanes whose walk has ended
     auto shade_hits = [&]() {
         if (st == kHit) {
-            advance_path<2>(w.rec, a, w.stack, nthreads, w.queue, sky, p, true, hit);
+            advance_path<2, kTree>(w.rec, a, w.stack, nthreads, w.queue, sky, p, br, true, hit);
             st = p.live ? kFresh : kParked;
         }
     };
@@ -695,11 +696,15 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PT_ST
                 PT_STAMP(sv1);
                 PT_STAMP_ADD(t_shade, sv1, sv0);
                 if (st == kParked) {
-                    const V3 sample = unwind_path(w.rec, w.stack, nthreads, p);
-                    out[out_index] = make_float4(sample.x, sample.y, sample.z, 0.0f);
-                    p.parked = false;
-                    st = kFree;
-                    ++done;
+                    V3 sample;
+                    if (settle_path<kTree>(w.rec, a, w.stack, nthreads, sky, p, br, sample)) {
+                        out[out_index] = make_float4(sample.x, sample.y, sample.z, 0.0f);
+                        p.parked = false;
+                        st = kFree;
+                        ++done;
+                    } else {
+                        st = kFresh; // a transmitted ray that was put aside: its walk starts below
+                    }
                 }
                 PT_STAMP(sv2);
                 PT_STAMP_ADD(t_settle, sv2, sv1);
@@ -979,9 +984,7 @@ size_t megakernel_lds_bytes(const LaunchArgs &a, uint32_t block, bool tree) {
         if (a.screened == 2u)
             bytes += (size_t)32 * a.scene.n_nodes;
     }
-    // (the branching kernel keeps its frames in private memory and leaves the
-    // bounce stack unused, but shares the layout)
-    (void)tree;
+    (void)tree; // (same layout: what a branching level puts aside is in private memory)
     bytes += ((size_t)2 * block * ((size_t)a.max_bounces + 1u) + 15u) & ~(size_t)15u;
     if (a.screened)
         bytes += (size_t)4 * block * kScreenQueue;
@@ -995,7 +998,7 @@ hipError_t launch_megakernel(const LaunchArgs &a, uint32_t block, bool tree,
     const uint64_t npix = (uint64_t)a.num_rows * a.framew;
     if (npix == 0 || a.spp == 0)
         return hipSuccess;
-    const uint64_t lanes = npix * (tree || a.lanes_per_pixel == 0 ? 1u : a.lanes_per_pixel);
+    const uint64_t lanes = npix * (a.lanes_per_pixel == 0 ? 1u : a.lanes_per_pixel);
     const uint32_t grid = (uint32_t)((lanes + block - 1) / block);
     const size_t lds = megakernel_lds_bytes(a, block, tree);
     if (tree && a.screened == 2u)
@@ -1023,11 +1026,11 @@ hipError_t launch_megakernel(const LaunchArgs &a, uint32_t block, bool tree,
                : launch_variant<false, false, 0>(a, grid, block, lds, stream);
 }
 
-template <bool kLds, int kScan, bool kStream = false>
+template <bool kLds, int kScan, bool kStream, bool kTree>
 static hipError_t launch_sample_variant(const LaunchArgs &a, uint32_t grid,
                                         uint32_t block, size_t lds_bytes,
                                         hipStream_t stream) {
-    auto kernel = kStream ? pt_streamkernel<kLds> : pt_samplekernel<kLds, kScan>;
+    auto kernel = kStream ? pt_streamkernel<kLds, kTree> : pt_samplekernel<kLds, kScan, kTree>;
     if (lds_bytes > 64u * 1024u) {
         hipError_t e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(kernel),
@@ -1067,23 +1070,30 @@ hipError_t launch_samplekernel(const LaunchArgs &a, uint32_t block,
     return launch_sample_dispatch(b, grid, block, lds, stream);
 }
 
-static hipError_t launch_sample_dispatch(const LaunchArgs &a, uint32_t grid, uint32_t block,
-                                         size_t lds, hipStream_t stream) {
+template <bool kTree>
+static hipError_t launch_sample_scan(const LaunchArgs &a, uint32_t grid, uint32_t block,
+                                     size_t lds, hipStream_t stream) {
     if (a.screened == 2u && a.stream_walks)
         return a.scene_in_lds
-                   ? launch_sample_variant<true, 2, true>(a, grid, block, lds, stream)
-                   : launch_sample_variant<false, 2, true>(a, grid, block, lds, stream);
+                   ? launch_sample_variant<true, 2, true, kTree>(a, grid, block, lds, stream)
+                   : launch_sample_variant<false, 2, true, kTree>(a, grid, block, lds, stream);
     if (a.screened == 2u)
         return a.scene_in_lds
-                   ? launch_sample_variant<true, 2>(a, grid, block, lds, stream)
-                   : launch_sample_variant<false, 2>(a, grid, block, lds, stream);
+                   ? launch_sample_variant<true, 2, false, kTree>(a, grid, block, lds, stream)
+                   : launch_sample_variant<false, 2, false, kTree>(a, grid, block, lds, stream);
     if (a.screened == 1u)
         return a.scene_in_lds
-                   ? launch_sample_variant<true, 1>(a, grid, block, lds, stream)
-                   : launch_sample_variant<false, 1>(a, grid, block, lds, stream);
+                   ? launch_sample_variant<true, 1, false, kTree>(a, grid, block, lds, stream)
+                   : launch_sample_variant<false, 1, false, kTree>(a, grid, block, lds, stream);
     return a.scene_in_lds
-               ? launch_sample_variant<true, 0>(a, grid, block, lds, stream)
-               : launch_sample_variant<false, 0>(a, grid, block, lds, stream);
+               ? launch_sample_variant<true, 0, false, kTree>(a, grid, block, lds, stream)
+               : launch_sample_variant<false, 0, false, kTree>(a, grid, block, lds, stream);
+}
+
+static hipError_t launch_sample_dispatch(const LaunchArgs &a, uint32_t grid, uint32_t block,
+                                         size_t lds, hipStream_t stream) {
+    return a.tree ? launch_sample_scan<true>(a, grid, block, lds, stream)
+                  : launch_sample_scan<false>(a, grid, block, lds, stream);
 }
 
 hipError_t launch_primary(const LaunchArgs &a, float *primary_hits, hipStream_t stream) {

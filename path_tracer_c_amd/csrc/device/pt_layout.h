@@ -122,6 +122,7 @@ struct LaunchArgs {
     uint32_t reshade_lanes; // ... second shading round of a service stage from this many lanes
     uint32_t lanes_per_pixel; // pixel-owner kernel: 1, or 2..64 (power of two) lanes
                               // sharing a pixel's samples (small row sets)
+    uint32_t tree;            // the scene has a branching material: kTree instantiations
     // sample-queue mode (pt_samplekernel / pt_sum_kernel)
     float *sample_buf;       // float4 per task: [sample][npix_pad]
     uint32_t *chunk_counter; // next chunk of 64 tasks; zeroed before a launch

@@ -99,8 +99,45 @@ __device__ __forceinline__ V3 shade_level(const F4 m0, const F4 m1, V3 child) {
 }
 
 // ---------------------------------------------------------------------------
-// Non-branching paths: every material has transparency <= 0 or >= 1.
+// Branching materials (0 < transparency < 1): incident_light calls itself
+// twice at such a hit, for the reflected and then for the transmitted ray
+// (src/renderer.c:45-52, 56-70), and a sample is a depth-first walk of a binary
+// tree.  A lane walks it as a path that can be RESUMED: at a branching hit it
+// follows the reflection and puts the transmitted ray aside (both are computed
+// from the same perturbed normal, at the hit); when the path ends, the unwind
+// (settle_path) returns values upwards only as far as the deepest level whose
+// transmitted ray is still waiting, keeps that level's reflected_Li in the
+// ray's place and sends the lane off along the transmitted ray; the next time
+// the unwind passes the level it has both children.  Draw order and arithmetic
+// are those of the recursion.  Everything else -- schedules, scans, the
+// 16-bit material stack -- is shared with the non-branching paths, which are
+// the special case of no level ever waiting.
 //
+// Per lane: two bit masks (bit k = recursion level k) and six words per level
+// in private memory, touched at branching hits only.
+// ---------------------------------------------------------------------------
+constexpr int kTreeFrames = 16; // >= PTGPU_MAX_BOUNCES_TREE + 1 levels
+
+template <bool kTree> struct Branches {};
+template <> struct Branches<true> {
+    uint32_t waiting = 0;  // level k's transmitted ray is in put_aside[k], not traced yet
+    uint32_t returned = 0; // level k's reflected_Li is in put_aside[k][0..2], its
+                           // transmission child is being evaluated
+    float put_aside[kTreeFrames][6];
+};
+
+// Le + lerp(reflected, transmitted, t) * albedo with both children at hand
+// (src/renderer.c:72-73)
+__device__ __forceinline__ V3 shade_level_both(const F4 m0, const F4 m1, V3 refl, V3 trans) {
+    V3 li = lerp(refl, trans, m1.w);
+#if defined(PT_FAST_MATH)
+    return madd(li, xyz(m0), xyz(m1));
+#else
+    return xyz(m1) + li * xyz(m0);
+#endif
+}
+
+// ---------------------------------------------------------------------------
 // Wave-level schedule.  Each pass of the loop has two stages:
 //   trace+shade  lanes that own a live ray scan the scene and shade the hit,
 //                which either yields the next ray or ends the path (the lane
@@ -162,11 +199,12 @@ __device__ __forceinline__ Hit scan_scene(const SceneRecords &rec, V3 o, V3 d,
 // either end the path (miss, depth limit, total internal reflection) or
 // produce the next ray (src/renderer.c:24-70).
 // `known` (wave-uniform): the closest hit of p's ray is already in `h_known`.
-template <int kScan>
+template <int kScan, bool kTree>
 __device__ __forceinline__ void
 advance_path(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
              uint32_t stack_stride, const ScreenQueue queue, V3 sky,
-             PathState &p, bool known = false, Hit h_known = Hit{-1.0f, -1}) {
+             PathState &p, Branches<kTree> &br, bool known = false,
+             Hit h_known = Hit{-1.0f, -1}) {
     PT_STAMP(stamp0);
     const Hit h = known ? h_known : scan_scene<kScan>(rec, p.o, p.d, queue);
     PT_STAMP(stamp1);
@@ -186,6 +224,21 @@ advance_path(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
 
         Bounce b;
         if (transparency < 1.0f) {
+            if constexpr (kTree) {
+                if (transparency > 0.0f) { // both children: the transmitted ray waits
+                    const Bounce later = refract_ray(p.d, n, sf.point);
+                    if (later.has_child) { // (total internal reflection: transmitted_Li = 0)
+                        const uint32_t k = p.depth - 1u;
+                        br.put_aside[k][0] = later.origin.x;
+                        br.put_aside[k][1] = later.origin.y;
+                        br.put_aside[k][2] = later.origin.z;
+                        br.put_aside[k][3] = later.direction.x;
+                        br.put_aside[k][4] = later.direction.y;
+                        br.put_aside[k][5] = later.direction.z;
+                        br.waiting |= 1u << k;
+                    }
+                }
+            }
             b = reflect_ray(p.d, n, sf.point);
         } else if (transparency > 0.0f) {
             b = refract_ray(p.d, n, sf.point);
@@ -222,6 +275,59 @@ __device__ __forceinline__ V3 unwind_path(const SceneRecords &rec,
         r = shade_level(rec.mat[2 * m + 0], rec.mat[2 * m + 1], r);
     }
     return clamp01(r);
+}
+
+// The unwind of a parked lane in a scene with branching materials: as
+// unwind_path, but only as far as the deepest level whose transmitted ray still
+// waits.  Returns true when the sample is complete (clamped value in `sample`),
+// false when the lane's walk goes on: p holds the transmitted ray and is live.
+template <bool kTree>
+__device__ __forceinline__ bool settle_path(const SceneRecords &rec, const LaunchArgs &a,
+                                            const uint16_t *stack, uint32_t stack_stride,
+                                            V3 sky, PathState &p, Branches<kTree> &br,
+                                            V3 &sample) {
+    if constexpr (!kTree) {
+        sample = unwind_path(rec, stack, stack_stride, p);
+        return true;
+    } else {
+        V3 r = p.r;
+        for (uint32_t k = p.depth; k-- > 0;) {
+            const uint32_t m = stack[k * stack_stride];
+            const F4 m0 = rec.mat[2 * m + 0], m1 = rec.mat[2 * m + 1];
+            const uint32_t bit = 1u << k;
+            if (br.waiting & bit) {
+                // r is level k's reflected_Li; its transmission child comes now
+                br.waiting &= ~bit;
+                const V3 o = V3{br.put_aside[k][0], br.put_aside[k][1], br.put_aside[k][2]};
+                const V3 d = V3{br.put_aside[k][3], br.put_aside[k][4], br.put_aside[k][5]};
+                if (k + 1u > a.max_bounces) {
+                    // that call has bounces > MAX_BOUNCES: sky, no ray (src/renderer.c:24-26)
+                    r = shade_level_both(m0, m1, r, sky);
+                    continue;
+                }
+                br.put_aside[k][0] = r.x;
+                br.put_aside[k][1] = r.y;
+                br.put_aside[k][2] = r.z;
+                br.returned |= bit;
+                p.o = o;
+                p.d = d;
+                p.r = splat(0.0f);
+                p.depth = k + 1u;
+                p.live = true;
+                p.parked = false;
+                return false;
+            }
+            if (br.returned & bit) { // r is level k's transmitted_Li
+                br.returned &= ~bit;
+                const V3 refl = V3{br.put_aside[k][0], br.put_aside[k][1], br.put_aside[k][2]};
+                r = shade_level_both(m0, m1, refl, r);
+                continue;
+            }
+            r = shade_level(m0, m1, r);
+        }
+        sample = clamp01(r);
+        return true;
+    }
 }
 
 // Wave-uniform decision of the settle stage (see run_paths).

@@ -688,6 +688,7 @@ int prepare_launch(const ptgpu_scene *s, size_t framew, size_t frameh,
         return fail(PTGPU_ERR_INVALID, "lanes_per_pixel must be 0 or a power of two up to 64");
     a->lanes_per_pixel = 1u; // render_common decides
     a->stream_walks = 0u;
+    a->tree = *tree ? 1u : 0u;
     a->chunk_batch = 1u; // the launcher decides
     a->primary_hits = nullptr;
     a->walk_budget = 0u;
@@ -942,12 +943,10 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
         mode = kPixelOwner;
     if (p->flags & PTGPU_FLAG_SAMPLE_QUEUE)
         mode = kSampleQueue;
-    if (tree)
-        mode = kPixelOwner; // the branching kernel exists in pixel-owner form only
-    const bool can_measure = may_pilot && a.counters != nullptr && !tree && total_spp >= 16 &&
+    const bool can_measure = may_pilot && a.counters != nullptr && total_spp >= 16 &&
                              npix * total_spp >= (1ull << 22);
     if (mode < 0 && !can_measure) // (the BVH scan is at its best in queue form)
-        mode = (a.screened == 2u && !tree) ? kSampleQueue : kPixelOwner;
+        mode = a.screened == 2u ? kSampleQueue : kPixelOwner;
 
     // How many lanes share a pixel in the pixel-owner kernel (pt_kernels.hip,
     // run_paths_split).  More lanes = more, shorter waves: a small row set (a
@@ -962,7 +961,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
     uint32_t owner_block = block; // workgroup size of pixel-owner launches
     auto choose_lanes = [&](bool may_fall_back_to_queue) {
         owner_block = block;
-        if (mode != kPixelOwner || tree)
+        if (mode != kPixelOwner)
             return;
         DeviceScratch *probe = nullptr;
         if (p->lanes_per_pixel != 0u) {
@@ -1214,7 +1213,7 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
                 q.screened = scan;
                 q.spp = count;
                 q.sample_offset = a.sample_offset + done_spp;
-                hipError_t e = L.megakernel(q, owner_block, false, stream);
+                hipError_t e = L.megakernel(q, owner_block, tree, stream);
                 if (e != hipSuccess)
                     return fail_hip(e, "megakernel launch (pilot)");
                 count_launch();

@@ -319,6 +319,68 @@ def test_branching_material_uses_the_tree_kernel(gpu, oracle):
     assert rays > 120 * 75 * 6 * 2
 
 
+@pytest.mark.parametrize("big", [False, True], ids=["8 objects", "150 objects"])
+def test_branching_scene_through_every_schedule_and_scan(gpu, torch_cuda, oracle, big):
+    """Scenes with 0 < transparency < 1 run the same kernels as the others: a
+    lane follows the reflection, the transmitted ray is put aside and the
+    unwind resumes there (pt_shade.h).  Every schedule (pixel owner with 1..64
+    lanes per pixel, sample queue, queue with resumable hierarchy walks), scan
+    form, settle threshold and the LDS scene copy give the oracle's frame, ray
+    for ray, also as progressive passes into an accumulator."""
+    A = gpu._abi
+    rng = np.random.default_rng(12)
+    w, h, spp, b = 56, 33, 5, 6
+    with gpu.HostScene(0) as s:
+        half = s.add_material((0.9, 0.9, 1.0), roughness=0.1, transparency=0.5)
+        frost = s.add_material((1.0, 0.8, 0.8), roughness=0.4, transparency=0.25,
+                               emission_color=(0.2, 0.1, 0.1), emission_strength=1.0)
+        thin = s.add_material((0.7, 1.0, 0.7), roughness=0.0, transparency=0.9)
+        s.add_sphere((0.3, 0.0, 3.0), 0.6, half)
+        s.add_sphere((-0.9, -0.5, 2.5), 0.4, frost)
+        s.add_sphere((0.9, 0.6, 2.8), 0.35, thin)
+        if big:
+            for i in range(140):
+                c = rng.uniform(-4, 4, 3) + np.array([0, 1, 7])
+                s.add_sphere(tuple(c), float(rng.uniform(0.1, 0.5)), [half, frost, thin, 0, 1][i % 5])
+        ref, rays = oracle.render_rows(s, w, h, spp=spp, max_bounces=b, seed=31)
+        assert rays > w * h * spp * 3
+        scans = [0x10, 0x20] + ([0x400] if big else [])
+        for scan in scans:
+            for sched in (0x80, 0x100, 0x140, 0x80 | 0x40):
+                for settle in (0, 1, 64):
+                    gpu.host.reset_stats()
+                    got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=31,
+                                           flags=scan | sched, settle_lanes=settle)
+                    st = gpu.host.read_stats()
+                    assert np.array_equal(got, ref), (hex(scan), hex(sched), settle)
+                    assert st.rays == rays and st.samples == w * h * spp, (hex(scan), hex(sched))
+            for lanes in (2, 4, 16, 64):
+                got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=31, flags=scan | 0x80,
+                                       lanes_per_pixel=lanes)
+                assert np.array_equal(got, ref), (hex(scan), lanes)
+        if big:                                   # whole walks in queue form
+            got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=31, flags=0xD00)
+            assert np.array_equal(got, ref)
+        # progressive: 2 + 3 samples, queue then owner, into the caller's accumulator
+        torch = torch_cuda
+        stream = torch.cuda.current_stream().cuda_stream
+        with gpu.DeviceScene(s) as d:
+            acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+            d.accumulate(acc.data_ptr(), w, h, gpu.make_params(spp=2, max_bounces=b, seed=31, flags=0x100), stream)
+            d.accumulate(acc.data_ptr(), w, h, gpu.make_params(spp=3, sample_offset=2, max_bounces=b, seed=31,
+                                                                flags=0x80), stream)
+            out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+            gpu.host.resolve(acc.data_ptr(), out.data_ptr(), w * h, stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), ref)
+        # the bounce limit cuts both children of a branching level off (k+1 > max_bounces)
+        for bb in (0, 1, 2):
+            ref_b, _ = oracle.render_rows(s, w, h, spp=2, max_bounces=bb, seed=5)
+            for sched in (0x80, 0x100):
+                got = gpu.render_frame(s, w, h, spp=2, max_bounces=bb, seed=5, flags=sched)
+                assert np.array_equal(got, ref_b), (bb, hex(sched))
+
+
 def test_nan_and_out_of_range_transparency(gpu, oracle):
     with gpu.HostScene(1) as s:
         weird = s.add_material((1, 1, 1), roughness=0.2, transparency=float("nan"))
@@ -881,15 +943,15 @@ def test_randomised_scenes_match_the_oracle(gpu, oracle, branching):
         with _random_scene(gpu, rng, branching) as s:
             w, h = int(rng.integers(8, 70)), int(rng.integers(5, 40))
             spp = int(rng.integers(1, 5))
-            b = int(rng.integers(0, 11 if not branching else 5))
-            flags = int(rng.choice([0, 0x40, 0x100, 0x20, 0x10, 0x140])) if not branching else int(rng.choice([0, 0x40, 0x10, 0x20]))
-            if branching and s.num_objects >= 64 and trial % 3 == 0:
-                flags |= 0x400                           # the branching kernel walks the hierarchy too
-            if not branching and s.num_objects >= 64 and trial % 2:
+            b = int(rng.integers(0, 11 if not branching else 7))   # (a tree of depth b+1 on the CPU)
+            flags = int(rng.choice([0, 0x40, 0x100, 0x20, 0x10, 0x140]))
+            if s.num_objects >= 64 and trial % 2:
                 # hierarchy scan: default schedule, pixel owner, queue with
                 # resumable walks (+ LDS copy), queue with whole walks
                 flags = int(rng.choice([0x400, 0x480, 0x500, 0x540, 0xD00]))
-            got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=trial, flags=flags)
+            lanes = int(rng.choice([0, 0, 2, 8, 64])) if branching else 0
+            got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=trial, flags=flags,
+                                   lanes_per_pixel=lanes)
             ref, _ = oracle.render_rows(s, w, h, spp=spp, max_bounces=b, seed=trial)
             assert np.array_equal(got, ref), (trial, w, h, spp, b, hex(flags), s.counts())
 
