@@ -60,8 +60,9 @@ extern "C" {
                                          LDS once per workgroup and scan it
                                          with broadcast LDS reads (falls back
                                          to the global scan if it cannot fit) */
-#define PTGPU_FLAG_FORCE_TREE 0x4u    /* use the branching (tree) kernel even
-                                         if no material needs it */
+#define PTGPU_FLAG_FORCE_TREE 0x4u    /* use the kernels' branching (tree)
+                                         instantiations even if no material
+                                         needs them */
 #define PTGPU_FLAG_NO_RAY_COUNT 0x8u  /* skip the ray/sample counters */
 #define PTGPU_FLAG_SCAN_PLAIN 0x10u   /* scheduling only: test every object in
                                          full */
@@ -141,7 +142,7 @@ extern "C" {
 
 /* limits */
 #define PTGPU_MAX_BOUNCES_PATH 62 /* non-branching kernel (LDS material stack) */
-#define PTGPU_MAX_BOUNCES_TREE 14 /* branching kernel (per-lane frame stack) */
+#define PTGPU_MAX_BOUNCES_TREE 14 /* scenes with a branching material (6 words put aside per level) */
 
 typedef struct ptgpu_params {
     uint32_t spp;           /* samples per pixel rendered by this call
