@@ -640,6 +640,37 @@ def test_schedule_is_measured_once_per_scene_and_cached(gpu, torch_cuda):
     assert schedule == "sample-queue" and scan in ("screened linear", "bvh")
 
 
+@pytest.mark.parametrize("n_extra", [0, 300], ids=["linear scans", "hierarchy"])
+def test_a_branching_scene_is_tuned_like_any_other(gpu, torch_cuda, oracle, n_extra):
+    """The pilots of ptgpu_scene_tune run a scene with 0 < transparency < 1
+    through the candidate scan forms and schedules too (round 1: pixel owner
+    only); the frame stays the forced pixel-owner frame, and two of its rows the
+    oracle's."""
+    torch = torch_cuda
+    rng = np.random.default_rng(8)
+    w, h = 512, 384
+    kw = dict(spp=24, max_bounces=5, seed=14)
+    with gpu.HostScene(1) as s:
+        half = s.add_material((0.9, 0.95, 1.0), roughness=0.05, transparency=0.6)
+        s.add_sphere((0.4, 0.2, 3.0), 0.7, half)
+        s.add_sphere((77.25 + n_extra, 3.5, 91.0), 0.5, half)       # content no other test uploads
+        for i in range(n_extra):
+            c = rng.uniform(-6, 6, 3) + np.array([0, 2, 10])
+            s.add_sphere(tuple(c), float(rng.uniform(0.1, 0.5)), half if i % 3 == 0 else 0)
+        with gpu.DeviceScene(s) as d:
+            assert d.branching
+            owner = render_device(gpu, torch, d, w, h, flags=0x80, **kw)
+            gpu.host.reset_stats()
+            d.tune(w, h, gpu.make_params(**kw))
+            assert gpu.host.read_stats().launches > 3               # pilots ran
+            tuned = render_device(gpu, torch, d, w, h, **kw)
+            assert d.schedule in ("pixel-owner", "sample-queue")
+            assert (d.scan == "bvh") == (n_extra > 0) or d.scan == "screened linear"
+        ref, _ = oracle.render_rows(s, w, h, 190, 192, **kw)
+    assert np.array_equal(tuned, owner)
+    assert np.array_equal(owner[190:192], ref[190:192])
+
+
 def test_queue_frames_on_two_streams_share_the_scratch_safely(gpu, torch_cuda):
     """Two frames enqueued back to back on different streams use the same
     per-device sample buffer; the second must wait for the first."""
