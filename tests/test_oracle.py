@@ -251,6 +251,27 @@ def test_golden_rays(pt, oracle, cfg):
     assert np.array_equal(mat[hit].astype(np.int64), z["material"][hit])
 
 
+def test_full_frame_digests_oracle_side(pt, oracle):
+    """tests/golden/full_frames.json holds digests of the BASELINE frames at
+    full size as rendered on the GPU.  Configuration 1 (256 x 256, 16 spp) is
+    small enough for the oracle to confirm here, without a GPU: the whole
+    frame and each of its eight bands.  (The others are minutes to hours of
+    CPU; the GPU tests compare sampled rows of them with the oracle.)"""
+    import hashlib
+    import json
+    want = json.loads((GOLDEN / "full_frames.json").read_text())["c1"]
+    c = pt.CONFIGS[1]
+    assert (want["width"], want["height"], want["spp"]) == (c["width"], c["height"], c["spp"])
+    with pt.HostScene(c["scene"]) as s:
+        frame, _ = oracle.render_rows(s, c["width"], c["height"], spp=c["spp"],
+                                      max_bounces=c["max_bounces"], seed=c["seed"])
+    h = frame.shape[0]
+    bands = [hashlib.sha256(frame[h * k // 8: h * (k + 1) // 8].tobytes()).hexdigest()[:16]
+             for k in range(8)]
+    assert bands == want["bands"]
+    assert hashlib.sha256(frame.tobytes()).hexdigest() == want["sha256"]
+
+
 def test_config1_ray_statistics_match_the_survey_probe(pt, oracle):
     """SURVEY.md section 6 measured 1.857 trace_ray calls per sample on this
     scene shape with the unmodified reference sources."""

@@ -1321,6 +1321,33 @@ def test_full_size_config5_rows_against_the_oracle(gpu, torch_cuda, oracle):
     assert np.array_equal(lds[400], ref[400])
 
 
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5"])
+def test_full_size_frames_keep_their_digests(gpu, torch_cuda, name):
+    """Every byte of the BASELINE configurations' full-size frames, held to the
+    digests in tests/golden/full_frames.json (a regression pin taken from a
+    build whose sampled rows equalled the oracle's -- the tests around this
+    one; tests/golden/make_full_frame_digests.py).  A second render with the
+    other schedule must give the same bytes."""
+    import importlib.util
+    import json
+    golden = Path(__file__).parent / "golden"
+    spec = importlib.util.spec_from_file_location("make_full_frame_digests",
+                                                  golden / "make_full_frame_digests.py")
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    want = json.loads((golden / "full_frames.json").read_text())[name]
+    key, passes = mk.FRAMES[name]
+    c = gpu.CONFIGS[key]
+    assert (want["width"], want["height"], want["spp"], want["max_bounces"], want["seed"]) == \
+        (c["width"], c["height"], c["spp"], c["max_bounces"], c["seed"])
+    got = mk.digests(mk.render_full(gpu, torch_cuda, key, passes))
+    assert got["bands"] == want["bands"] and got["sha256"] == want["sha256"]
+    if name in ("c2", "c5"):                   # the schedule the library does not pick by itself
+        other = gpu._abi.FLAG_SAMPLE_QUEUE if name == "c2" else gpu._abi.FLAG_PIXEL_OWNER
+        got = mk.digests(mk.render_full(gpu, torch_cuda, key, passes, flags=other))
+        assert got["bands"] == want["bands"] and got["sha256"] == want["sha256"], hex(other)
+
+
 # ---- BASELINE.json configs[2..4] at FULL size (round 2) ---------------------------------
 def _oracle_rows(oracle, scene, w, h, rows, threads=3, **kw):
     """The oracle on a few single rows, one thread per row (the stream is a
