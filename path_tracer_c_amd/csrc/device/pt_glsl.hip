@@ -108,23 +108,24 @@ struct GHit {
 
 // :158-192.  The scene records keep the scene's object order; the shader's
 // two arrays are that order filtered by kind, hence the two passes.
+// The shader rewrites point, normal and material at every candidate it accepts;
+// all three are functions of the accepted (distance, object) alone, so the
+// scan keeps only that pair and the record is filled in once, after the loop,
+// with the very same operations: same bits, a normalisation per ray instead
+// of one per accepted candidate.
 __device__ __forceinline__ GHit g_trace(const SceneDesc &sc, V3 origin, V3 direction) {
-    GHit h;
-    h.distance = -1.0f;
-    h.point = h.normal = splat(0.0f);
-    h.material = 0u;
+    float distance = -1.0f;
+    uint32_t object = 0xFFFFFFFFu; // nothing accepted yet
     for (uint32_t i = 0; i < sc.n_obj; ++i) {
         const F4 g = sc.geom[i];
         if (__builtin_bit_cast(uint32_t, g.w) & 0x80000000u)
             continue; // a triangle record
         const V3 c = V3{g.x, g.y, g.z};
         const float dist = g_ray_sphere(origin - c, direction, g.w);
-        if (h.distance > 0.0f && (dist < 0.0f || dist >= h.distance))
+        if (distance > 0.0f && (dist < 0.0f || dist >= distance))
             continue;
-        h.distance = dist;
-        h.point = origin + direction * dist;
-        h.normal = g_normalize(h.point - c);
-        h.material = sc.meta[i] & kMetaMaterialMask;
+        distance = dist;
+        object = i;
     }
     if (sc.n_tri != 0u) {
         for (uint32_t i = 0; i < sc.n_obj; ++i) {
@@ -135,15 +136,27 @@ __device__ __forceinline__ GHit g_trace(const SceneDesc &sc, V3 origin, V3 direc
             const F4 v0 = sc.tri[4 * k + 0], e1 = sc.tri[4 * k + 1], e2 = sc.tri[4 * k + 2];
             const float dist = g_ray_triangle(origin, direction, V3{v0.x, v0.y, v0.z},
                                               V3{e1.x, e1.y, e1.z}, V3{e2.x, e2.y, e2.z});
-            if (h.distance > 0.0f && (dist < 0.0f || dist >= h.distance))
+            if (distance > 0.0f && (dist < 0.0f || dist >= distance))
                 continue;
-            h.distance = dist;
-            h.point = origin + direction * dist;
-            const F4 nn = sc.tri[4 * k + 3]; // normalize(cross(v0 - v1, v0 - v2)), uploaded
+            distance = dist;
+            object = i;
+        }
+    }
+    GHit h;
+    h.distance = distance;
+    h.point = h.normal = splat(0.0f);
+    h.material = 0u;
+    if (object != 0xFFFFFFFFu && !(distance < 0.0f)) { // (a miss is never looked at: :206-209)
+        const F4 g = sc.geom[object];
+        h.point = origin + direction * distance;
+        h.material = sc.meta[object] & kMetaMaterialMask;
+        if (!(__builtin_bit_cast(uint32_t, g.w) & 0x80000000u)) {
+            h.normal = g_normalize(h.point - V3{g.x, g.y, g.z});
+        } else {
+            const F4 nn = sc.tri[4 * sc.link[object] + 3]; // normalize(cross(v0 - v1, v0 - v2)), uploaded
             const V3 normal = V3{nn.x, nn.y, nn.z};
             const float side = dot(direction, normal) < 0.0f ? 1.0f : -1.0f;
             h.normal = normal * side;
-            h.material = sc.meta[i] & kMetaMaterialMask;
         }
     }
     return h;
