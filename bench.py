@@ -428,6 +428,38 @@ def main():
                         "the default build stays bit-exact"}
             local[:h].copy_(exact_frame)
             del exact_frame, diff
+        if world == 1 and args.workload == "c5":
+            # BASELINE configs[4] asks for this comparison by name: the 1000-sphere scene
+            # scanned linearly with the scene records read through the scalar data cache
+            # (global memory: "HBM linear scan") against the per-workgroup LDS copy, both in
+            # the sample-queue schedule (ballot + prefix-sum refill of finished lanes = the
+            # live-ray compaction), beside the hierarchy walk the library picks.  16 spp each.
+            A = pt._abi
+            forms = [("screened linear scan, records from global memory (scalar loads)", A.FLAG_SCAN_SCREENED | A.FLAG_SAMPLE_QUEUE),
+                     ("screened linear scan, records from an LDS tile", A.FLAG_SCAN_SCREENED | A.FLAG_SAMPLE_QUEUE | A.FLAG_SCENE_LDS),
+                     ("plain linear scan, records from global memory", A.FLAG_SCAN_PLAIN | A.FLAG_SAMPLE_QUEUE),
+                     ("plain linear scan, records from an LDS tile", A.FLAG_SCAN_PLAIN | A.FLAG_SAMPLE_QUEUE | A.FLAG_SCENE_LDS),
+                     ("screened linear scan, pixel-owner schedule (no compaction)", A.FLAG_SCAN_SCREENED | A.FLAG_PIXEL_OWNER),
+                     ("hierarchy, resumable walks (the library's choice)", A.FLAG_SCAN_BVH | A.FLAG_SAMPLE_QUEUE)]
+            table = []
+            keep = local.clone()
+            for label, f in forms:
+                q = pt.make_params(spp=16, **{**base, "flags": base["flags"] | f})
+                dscene.render(local.data_ptr(), w, h, q, stream)
+                torch.cuda.synchronize()
+                pt.host.reset_stats()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dscene.render(local.data_ptr(), w, h, q, stream)
+                e1.record()
+                torch.cuda.synchronize()
+                sf = pt.host.read_stats()
+                ms = e0.elapsed_time(e1)
+                table.append({"form": label, "ms_per_16spp": ms, "Mray_per_s": sf.rays / ms / 1e3,
+                              "lane_utilisation": sf.rays / (64.0 * sf.wave_iters) if sf.wave_iters else None})
+            line["config"]["scan_forms_16spp"] = table
+            local.copy_(keep)
+            del keep
         if world == 1 and not progressive:
             # end to end through the host-buffer entry point (PCIe included):
             # scene upload + kernel + frame download; reported, never `value`
