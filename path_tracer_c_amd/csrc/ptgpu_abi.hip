@@ -122,10 +122,40 @@ pt::V3 to_v3(const vec3s &v) { return pt::V3{v.x, v.y, v.z}; }
 // as (centre, -r^2).  Only the conservative screen of the large-scene scan
 // uses it; a degenerate or non-finite triangle gets an infinite radius
 // (always kept), so screening can never drop what the exact test would hit.
+// A triangle the screen and the hierarchy must never cull: (0, 0, 0, -inf) keeps
+// every ray in screen_keep and has no finite box (bvh_build.hpp: `unbounded`).
+pt::F4 never_culled_triangle_record() {
+    return pt::F4{0.0f, 0.0f, 0.0f, -std::numeric_limits<float>::infinity()};
+}
+
 pt::F4 bounding_sphere_record(const triangle &t) {
     const double p[3][3] = {{t.v0.x, t.v0.y, t.v0.z},
                             {t.v1.x, t.v1.y, t.v1.z},
                             {t.v2.x, t.v2.y, t.v2.z}};
+    // Needles.  The reference's triangle test (glms_ray_triangle, src/ray.c:42)
+    // divides by det = e1 . (d x e2), whose rounding error is a few 1e-7 of
+    // |e1| |e2| whatever the ray.  When the edges are parallel to within that
+    // (a sliver: v1 ~ v2, or a zero-area triangle) det is noise for EVERY ray,
+    // u, v and the distance are noise too, and the test "hits" the triangle
+    // wherever a ray comes close to the LINE through it, however far from the
+    // three vertices -- found by the round-2 fuzz: a sliver of 67 units with
+    // v1 and v2 6e-5 apart, hit 90 units beyond its end.  No finite bound
+    // holds such hits, so a triangle whose edges enclose an angle below 1e-2
+    // is tested for every ray, as the reference tests everything.  (Wider
+    // triangles keep their bounds: there the noise needs a ray that grazes the
+    // triangle's plane to ~1e-5 from many edge lengths away.)
+    {
+        const float e1f[3] = {t.v1.x - t.v0.x, t.v1.y - t.v0.y, t.v1.z - t.v0.z}; // as uploaded
+        const float e2f[3] = {t.v2.x - t.v0.x, t.v2.y - t.v0.y, t.v2.z - t.v0.z};
+        const double a[3] = {e1f[0], e1f[1], e1f[2]}, b[3] = {e2f[0], e2f[1], e2f[2]};
+        const double n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2],
+                             a[0] * b[1] - a[1] * b[0]};
+        const double n2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+        const double a2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+        const double b2 = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
+        if (!(n2 >= 1e-4 * a2 * b2) || !(a2 * b2 > 0.0)) // sin^2 < 1e-4, zero edge, NaN
+            return never_culled_triangle_record();
+    }
     auto dist2 = [](const double *a, const double *b) {
         double s = 0;
         for (int i = 0; i < 3; ++i)
@@ -169,7 +199,7 @@ pt::F4 bounding_sphere_record(const triangle &t) {
     r2f = std::nextafter(r2f, std::numeric_limits<float>::infinity());
     if (!(r2f == r2f) || !std::isfinite(cf[0]) || !std::isfinite(cf[1]) ||
         !std::isfinite(cf[2]))
-        return pt::F4{0.0f, 0.0f, 0.0f, -std::numeric_limits<float>::infinity()};
+        return never_culled_triangle_record();
     return pt::F4{cf[0], cf[1], cf[2], -r2f};
 }
 

@@ -987,6 +987,55 @@ def test_randomised_scenes_match_the_oracle(gpu, oracle, branching):
             assert np.array_equal(got, ref), (trial, w, h, spp, b, hex(flags), s.counts())
 
 
+def _scene_from_json(gpu, path):
+    """A scene dumped by a fuzz reproduction (tools/repro_fast.py) -> HostScene."""
+    import json
+    d = json.loads(Path(path).read_text())
+    s = gpu.HostScene()
+    s.set_sky(*d["sky"])
+    for m in d["mats"]:
+        s.add_material(tuple(m["albedo"]), roughness=m["roughness"], emission_color=tuple(m["em"]),
+                       emission_strength=m["es"], transparency=m["t"], refractive_index=m["ior"])
+    for o in d["objs"]:
+        if o["k"] == "s":
+            s.add_sphere(tuple(o["c"]), o["r"], o["m"])
+        else:
+            s.add_triangle(*[tuple(v) for v in o["v"]], o["m"])
+    return s, d
+
+
+def test_a_sliver_is_hit_far_beyond_its_end_and_no_scan_form_may_cull_it(gpu, oracle):
+    """Found by the round-2 fuzz (seed 555, trial 7617 of the tolerance mode's
+    consistency test; the exact build had the same hole).  Object 34 of this
+    scene is a sliver, 67 units long with v1 and v2 6e-5 apart: the
+    determinant of the reference's triangle test is rounding noise for every
+    ray, and the third ray of pixel (11, 30) "hits" it at distance 320.0, ninety
+    units beyond its end -- the oracle says so, and so does the plain scan.
+    The screen and the hierarchy culled the sliver by its (correct) bounds and
+    found the sphere behind it.  Needles are now never culled
+    (bounding_sphere_record, csrc/ptgpu_abi.hip)."""
+    A = gpu._abi
+    s, d = _scene_from_json(gpu, GOLDEN / "scenes" / "screen_hole_r2.json")
+    with s:
+        w, h, kw = d["w"], d["h"], d["kw"]
+        ref, _ = oracle.render_rows(s, w, h, **kw)
+        o, dr = oracle.sample_rays(s, w, h, 11, 30, 0, **kw)
+        want = oracle.trace_rays(s, o, dr)
+        assert len(o) == 3 and want[0][2] == np.float32(320.0)
+        for scan in (A.FLAG_SCAN_PLAIN, A.FLAG_SCAN_SCREENED, A.FLAG_SCAN_BVH):
+            got = gpu.trace_rays(s, o, dr, scan)
+            assert np.array_equal(bits(got[0]), bits(want[0])), hex(scan)
+            assert np.array_equal(got[3], want[3]), hex(scan)
+            for sched in (A.FLAG_PIXEL_OWNER, A.FLAG_SAMPLE_QUEUE):
+                frame = gpu.render_frame(s, w, h, flags=scan | sched, **kw)
+                assert np.array_equal(frame, ref), (hex(scan), hex(sched))
+                fast = gpu.render_frame(s, w, h, flags=scan | sched | A.FLAG_FAST_MATH, **kw)
+                assert np.array_equal(fast[30, 11], ref[30, 11]), (hex(scan), hex(sched))
+        with gpu.DeviceScene(s) as dev:
+            nodes, depth = dev.hierarchy
+            assert nodes > 0                         # the other 70 objects are in the hierarchy
+
+
 @pytest.mark.parametrize("scale", [1e-20, 1e-12, 1e15], ids=["denormal r*r", "tiny", "huge"])
 def test_extreme_scales_match_the_oracle(gpu, oracle, scale):
     """Radii of 1e-20 make r*r a binary32 denormal; 1e15 puts squared
