@@ -958,9 +958,14 @@ def _random_scene(gpu, rng, branching):
             e1 = rng.normal(0, 2, 3) * scale
             e2 = rng.normal(0, 2, 3) * scale
             s.add_triangle(tuple(c), tuple(c + e1), tuple(c + e2), m)
-        else:                                       # sliver / degenerate triangle
+        else:                                       # sliver / degenerate / thin triangle
             e1 = rng.normal(0, 2, 3) * scale
-            s.add_triangle(tuple(c), tuple(c + e1), tuple(c + e1 * (1 + 1e-6)), m)
+            if rng.integers(2):
+                s.add_triangle(tuple(c), tuple(c + e1), tuple(c + e1 * (1 + 1e-6)), m)
+            else:                                   # edges 10^-0.5 .. 10^-4 rad apart: both sides of
+                side = np.cross(e1, rng.normal(0, 1, 3))     # the never-culled threshold (1e-2)
+                side *= np.linalg.norm(e1) / max(np.linalg.norm(side), 1e-30) * 10 ** -rng.uniform(0.5, 4)
+                s.add_triangle(tuple(c), tuple(c + e1), tuple(c + e1 * rng.uniform(0.3, 1.5) + side), m)
     if rng.integers(3) == 0:                        # camera inside a big sphere
         s.add_sphere((0, 0, 0), 20.0 * scale, int(rng.integers(n_mat)))
     return s
