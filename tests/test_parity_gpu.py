@@ -1039,6 +1039,22 @@ def test_a_sliver_is_hit_far_beyond_its_end_and_no_scan_form_may_cull_it(gpu, or
         with gpu.DeviceScene(s) as dev:
             nodes, depth = dev.hierarchy
             assert nodes > 0                         # the other 70 objects are in the hierarchy
+    # nothing but needles (and one sphere): the hierarchy is empty, every object is
+    # tested for every ray, and the scan forms still agree with the oracle
+    rng = np.random.default_rng(4)
+    with gpu.HostScene() as s:
+        s.set_sky(0.3, 0.5, 0.7)
+        m = s.add_material((0.8, 0.6, 0.4), roughness=0.3)
+        for i in range(80):
+            c = rng.normal(0, 3, 3) + np.array([0, 0, 8])
+            e1 = rng.normal(0, 2, 3)
+            s.add_triangle(tuple(c), tuple(c + e1), tuple(c + e1 * (1 + 10 ** -rng.uniform(2.5, 7))), m)
+        s.add_sphere((0, -1, 9), 1.5, m)
+        ref, _ = oracle.render_rows(s, 64, 40, spp=2, max_bounces=3, seed=3)
+        for scan in (A.FLAG_SCAN_PLAIN, A.FLAG_SCAN_SCREENED, A.FLAG_SCAN_BVH):
+            for sched in (A.FLAG_PIXEL_OWNER, A.FLAG_SAMPLE_QUEUE):
+                got = gpu.render_frame(s, 64, 40, spp=2, max_bounces=3, seed=3, flags=scan | sched)
+                assert np.array_equal(got, ref), (hex(scan), hex(sched))
 
 
 @pytest.mark.parametrize("scale", [1e-20, 1e-12, 1e15], ids=["denormal r*r", "tiny", "huge"])
