@@ -271,6 +271,12 @@ struct ScreenQueue {
     uint32_t *stack;  // BVH scan: this lane's traversal stack, same stride
 };
 
+#ifndef PT_BOX_SLACK
+#define PT_BOX_SLACK 1.0e-4f
+#endif
+#ifndef PT_SCREEN_MARGIN
+#define PT_SCREEN_MARGIN 0x1.0p-16f
+#endif
 __device__ __forceinline__ bool screen_keep(const F4 g, V3 o, V3 d) {
     // |w| is r^2 of the sphere itself, or of a triangle's bounding sphere:
     // one branch-free test for every record, so the eight fetches of a block
@@ -281,7 +287,7 @@ __device__ __forceinline__ bool screen_keep(const F4 g, V3 o, V3 d) {
     const float dpp = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
     const float perp2 = __builtin_fmaf(-ddp, ddp, dpp);
     // certainly misses iff (perp2 - r2) - 2^-16 * (dpp + r2) > 0
-    const float excess = __builtin_fmaf(dpp + r2, -0x1.0p-16f, perp2 - r2);
+    const float excess = __builtin_fmaf(dpp + r2, -PT_SCREEN_MARGIN, perp2 - r2);
     return !(excess > 0.0f);
 }
 
@@ -527,7 +533,7 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
         // fminf/fmaxf drop a NaN operand (0 * inf on a box face)
         enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
         const float leave = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-        const float slack = 1.0e-4f * (fabsf(enter) + fabsf(leave));
+        const float slack = PT_BOX_SLACK * (fabsf(enter) + fabsf(leave));
         const bool missed = (enter == __builtin_inff()) | (leave == -__builtin_inff()) |
                             (leave - enter < -slack) | (leave < -slack) |
                             (enter - slack > u.best);
@@ -720,7 +726,7 @@ __device__ __forceinline__ void bvh_walk_quantum(const SceneRecords &rec,
         const float z0 = (lo.z - o.z) * w.inv.z, z1 = (hi.z - o.z) * w.inv.z;
         enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
         const float leave = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-        const float slack = 1.0e-4f * (fabsf(enter) + fabsf(leave));
+        const float slack = PT_BOX_SLACK * (fabsf(enter) + fabsf(leave));
         const bool missed = (enter == __builtin_inff()) | (leave == -__builtin_inff()) |
                             (leave - enter < -slack) | (leave < -slack) |
                             (enter - slack > w.u.best);
