@@ -65,10 +65,17 @@ extern "C" {
                                          needs them */
 #define PTGPU_FLAG_NO_RAY_COUNT 0x8u  /* skip the ray/sample counters */
 #define PTGPU_FLAG_SCAN_PLAIN 0x10u   /* scheduling only: test every object in
-                                         full */
+                                         full (no culling of any kind: the
+                                         reference's scan, object for object) */
 #define PTGPU_FLAG_SCAN_SCREENED 0x20u /* scheduling only: conservative screen
                                          + per-lane queues.  Same image either
-                                         way.  Without a SCAN flag the form is
+                                         way (one stated limit of the screen
+                                         and the hierarchy, which decide by
+                                         geometry: a ray lying in a triangle's
+                                         plane to ~2e-4 rad, where the
+                                         reference's triangle test is rounding
+                                         noise -- DESIGN.md section 4.1).
+                                         Without a SCAN flag the form is
                                          timed on a scene's first large render
                                          (8 samples per candidate form) and
                                          remembered; smaller renders go by
