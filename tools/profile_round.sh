@@ -17,6 +17,9 @@ for w in c2 c5; do
   say "rocprofv3 --kernel-trace --stats $w"
   rocprofv3 --kernel-trace --stats -d "$out/trace_$w" -o t --output-format csv -- python3 bench.py --workload $w --steps 5 --warmup 1 --no-cpu-baseline > "$out/trace_$w.log" 2>&1 || say "trace $w FAILED"
   cp "$out/trace_$w"/t_kernel_stats.csv "$out/${w}_kernel_stats.csv" 2>/dev/null || find "$out/trace_$w" -name "*kernel_stats.csv" -exec cp {} "$out/${w}_kernel_stats.csv" \;
+  # the dominant kernel's launches one by one (the --stats average mixes pilots, timed steps and side measurements)
+  k="pt::pt_megakernel<false, false, 0>"; [ $w = c5 ] && k="pt::pt_streamkernel<false, false>"
+  python3 tools/dispatch_list.py "$(find $out/trace_$w -name '*kernel_trace.csv' | head -1)" "$k" > "$out/${w}_dispatches.csv" 2>&1
 done
 say "HBM traffic passes (FETCH_SIZE, WRITE_SIZE) c2"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/hbm_c2_f" -o p --output-format csv -- python3 tools/one_render.py c2 0x280 256 3 8 > "$out/hbm_c2_f.log" 2>&1
