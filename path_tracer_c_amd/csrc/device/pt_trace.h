@@ -245,8 +245,11 @@ PT_HD Hit poisoned_hit(const SceneRecords &rec, V3 o, V3 d) {
 //            either formulation, direction normalisation error included) a
 //            sphere is dropped only if |dp_perp|^2 - r^2 > err.  NaN/overflow
 //            compare false -> kept.  A triangle is screened through its
-//            bounding sphere (radius inflated by 1e-3 at upload, far more
-//            than Moeller-Trumbore's own edge tolerance).
+//            bounding sphere (radius inflated by 1e-3 at upload); a needle --
+//            edges closer than 1e-2 rad, where the reference's test is noise
+//            for every ray -- carries an infinite radius and is always kept
+//            (csrc/ptgpu_abi.hip, bounding_sphere_record; the limit that
+//            remains for rays lying in a triangle's plane: DESIGN.md 4.1).
 //   resolve  each lane appends the indices of its surviving objects, in
 //            ascending order, to its own queue in LDS (kScreenQueue entries);
 //            when some lane's queue could overflow during the next block of
