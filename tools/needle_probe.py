@@ -38,6 +38,16 @@ for sin_angle in [float(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2
             origin = target + rng.normal(0, 1, (n_rays, 3)) * scale * 10 ** rng.uniform(0, 2, (n_rays, 1))
             d = target - origin
             d /= np.linalg.norm(d, axis=1, keepdims=True)
+            if "-inplane" in sys.argv:
+                # rays lying (almost) in the aimed triangle's plane: direction = an in-plane direction tilted out of
+                # the plane by 1e-7 .. 1e-2 rad, passing the triangle within an edge length or so
+                nrm = np.cross(e1, e2); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+                inp = np.cross(nrm, rng.normal(0, 1, (n_rays, 3))); inp /= np.linalg.norm(inp, axis=1, keepdims=True)
+                tilt = 10 ** rng.uniform(-7, -2, (n_rays, 1)) * rng.choice([-1, 1], (n_rays, 1))
+                d = inp + nrm * tilt
+                d /= np.linalg.norm(d, axis=1, keepdims=True)
+                through = c + e1 * rng.uniform(-1, 2, (n_rays, 1)) + e2 * rng.uniform(-1, 2, (n_rays, 1))
+                origin = through - d * np.linalg.norm(e1, axis=1, keepdims=True) * 10 ** rng.uniform(0, 2, (n_rays, 1))
             o32 = origin.astype(np.float32); d32 = d.astype(np.float32)
             plain = pt.trace_rays(s, o32, d32, A.FLAG_SCAN_PLAIN)
             for name, f in (("screened", A.FLAG_SCAN_SCREENED), ("bvh", A.FLAG_SCAN_BVH)):
