@@ -1057,6 +1057,43 @@ def test_a_sliver_is_hit_far_beyond_its_end_and_no_scan_form_may_cull_it(gpu, or
                 assert np.array_equal(got, ref), (hex(scan), hex(sched))
 
 
+def test_a_floor_of_coplanar_triangles_is_one_picture_in_every_scan_form(gpu, oracle):
+    """Diffuse bounces off a triangulated floor start rays that lie almost in
+    the plane of every other floor triangle -- the regime where the reference's
+    triangle test is least like geometry.  The floor is tilted
+    off every axis so that no product in the test is exactly zero.  Plain,
+    screened and hierarchy scans must give one picture, and two of its rows
+    the oracle's (tools/floor_probe.py does the same at 1080p / 256 spp)."""
+    A = gpu._abi
+    rng = np.random.default_rng(5)
+    ax = np.array([0.3, 0.1, 0.2]); ang = np.linalg.norm(ax); k = ax / ang
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+    n, w, h = 20, 480, 270
+    with gpu.HostScene() as s:
+        s.set_sky(0.5, 0.7, 0.9)
+        floor = s.add_material((0.8, 0.8, 0.7), roughness=1.0)
+        shiny = s.add_material((0.9, 0.9, 0.9), roughness=0.05)
+        size = 40.0 / n
+        for i in range(n):
+            for j in range(n):
+                x0, z0 = -20 + i * size, 2 + j * size
+                p = [R @ np.array(v) for v in ((x0, -1.5, z0), (x0 + size, -1.5, z0),
+                                               (x0, -1.5, z0 + size), (x0 + size, -1.5, z0 + size))]
+                s.add_triangle(tuple(p[0]), tuple(p[1]), tuple(p[2]), floor)
+                s.add_triangle(tuple(p[1]), tuple(p[3]), tuple(p[2]), floor)
+        for _ in range(12):
+            c = R @ np.array([rng.uniform(-8, 8), rng.uniform(-1, 2), rng.uniform(5, 25)])
+            s.add_sphere(tuple(c), float(rng.uniform(0.4, 1.2)), shiny if rng.integers(2) else floor)
+        kw = dict(spp=32, max_bounces=8, seed=3)
+        plain = gpu.render_frame(s, w, h, flags=A.FLAG_SCAN_PLAIN, **kw)
+        for f in (A.FLAG_SCAN_SCREENED, A.FLAG_SCAN_BVH, A.FLAG_SCAN_BVH | A.FLAG_PIXEL_OWNER):
+            assert np.array_equal(gpu.render_frame(s, w, h, flags=f, **kw), plain), hex(f)
+        for y in (150, 260):
+            ref, _ = oracle.render_rows(s, w, h, y, y + 1, **kw)
+            assert np.array_equal(plain[y], ref[y]), y
+
+
 @pytest.mark.parametrize("scale", [1e-20, 1e-12, 1e15], ids=["denormal r*r", "tiny", "huge"])
 def test_extreme_scales_match_the_oracle(gpu, oracle, scale):
     """Radii of 1e-20 make r*r a binary32 denormal; 1e15 puts squared
