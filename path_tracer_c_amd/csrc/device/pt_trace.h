@@ -235,6 +235,17 @@ PT_HD Hit poisoned_hit(const SceneRecords &rec, V3 o, V3 d) {
     return h;
 }
 
+// glms_ray_sphere assumes a unit direction (src/ray.c:21 hands it whatever
+// trace_ray was given); with any other length its roots are not where the ray
+// meets the sphere, and no screen or box can say which objects it will "hit".
+// The renderer only ever passes normalised directions (|d|^2 = 1 +- 3e-7) or,
+// rarely, the zero vector glms_vec3_normalize returns for a tiny one; a caller
+// of trace_ray may pass anything.  Such rays get the reference's own scan.
+PT_HD bool direction_is_not_unit(V3 d) {
+    const float len2 = d.x * d.x + d.y * d.y + d.z * d.z;
+    return !(len2 >= 1.0f - 1.0e-5f && len2 <= 1.0f + 1.0e-5f); // (NaN: true)
+}
+
 // The same scan for large scenes, in two phases that keep the result (and the
 // order objects are accepted in) identical:
 //   screen   a wave-uniform pass over all objects, eight records fetched at a
@@ -362,6 +373,12 @@ __device__ __forceinline__ Hit closest_hit_screened(const SceneRecords &rec,
     for (; i < n; ++i)
         push(screen_keep(rec.geom[i], o, d), i);
     resolve();
+    // (the screen is geometry for a unit direction; any other gets the plain scan)
+    const bool odd = direction_is_not_unit(d);
+    if (__any(odd)) {
+        if (odd)
+            h = closest_hit(rec, o, d);
+    }
     return h;
 }
 
@@ -519,10 +536,11 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
     // 0/0 root poisons the next ray of the path).  Boxes mean nothing for
     // it, so such a lane does the reference's sequential walk instead.
     // (the sum is non-finite iff some component is, or the sum overflows --
-    // then the fallback is merely slower, still exact)
+    // then the fallback is merely slower, still exact)  The same goes for a
+    // direction that is not of unit length (direction_is_not_unit above).
     const float probe = (fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) +
                         (fabsf(d.x) + fabsf(d.y) + fabsf(d.z));
-    const bool poisoned = !(probe < __builtin_inff());
+    const bool poisoned = !(probe < __builtin_inff()) || direction_is_not_unit(d);
     walking = !poisoned;
 
     const V3 inv = V3{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y),
@@ -658,7 +676,7 @@ struct BvhWalk {
 __device__ __forceinline__ bool ray_is_poisoned(V3 o, V3 d) {
     const float probe = (fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) +
                         (fabsf(d.x) + fabsf(d.y) + fabsf(d.z));
-    return !(probe < __builtin_inff());
+    return !(probe < __builtin_inff()) || direction_is_not_unit(d);
 }
 
 // Starts (or, with min_index > 0, restarts) a walk.  Objects outside the

@@ -2039,6 +2039,110 @@ def test_fast_math_randomised_scenes_are_the_same_picture_in_every_scan_form(gpu
                 assert np.array_equal(got, ref), (trial, hex(f), w, h, kw, s.counts())
 
 
+def test_trace_ray_with_a_direction_that_is_not_of_unit_length(gpu, oracle):
+    """glms_ray_sphere assumes a unit direction; trace_ray hands it whatever it
+    was given (src/ray.c:21), and the roots it then reports are not where the
+    ray meets the sphere -- no screen or hierarchy can bound them.  Such rays
+    get the reference's own scan, whatever scan form was asked for (found by
+    the randomised ray test: |d| = 0.78, screened scan, another object)."""
+    A = gpu._abi
+    rng = np.random.default_rng(8)
+    n = 4000
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:, 2] = np.abs(d[:, 2])
+    d = (d * rng.choice([0.0, 0.3, 0.776, 0.999, 1.001, 2.0, 17.0], (n, 1))).astype(f32)
+    o = rng.normal(0, 1, (n, 3)).astype(f32)
+    for cfg in (5, 2):
+        with gpu.HostScene(cfg) as s:
+            want = oracle.trace_rays(s, o, d)
+            for scan in (0, A.FLAG_SCAN_PLAIN, A.FLAG_SCAN_SCREENED) + ((A.FLAG_SCAN_BVH,) if cfg == 5 else ()):
+                got = gpu.trace_rays(s, o, d, scan)           # 0: the library's choice by object count
+                assert np.array_equal(bits(got[0]), bits(want[0])), (cfg, hex(scan))
+                assert np.array_equal(got[3][want[0] >= 0], want[3][want[0] >= 0]), (cfg, hex(scan))
+            lib = gpu.lib()                                # the legacy single-ray entry point too
+            for j in (1, 2, 3):
+                hit = lib.trace_ray(A.Vec3(*o[j]), A.Vec3(*d[j]), C.byref(s.c))
+                assert np.float32(hit.distance).view(np.uint32) == want[0][j].view(np.uint32)
+
+
+def test_randomised_rays_through_randomised_scenes_in_every_scan_form(gpu, oracle):
+    """ptgpu_trace_rays on the fuzz generator's hostile scenes with rays of
+    every kind a render produces and some it does not: from inside and
+    outside, from object surfaces, unnormalised, zero, huge, with a NaN or an
+    infinite component -- plain, screened and hierarchy scans against the
+    oracle's trace_ray, distance bits, point, normal and material."""
+    A = gpu._abi
+    rng = np.random.default_rng(int(os.environ.get("PT_FUZZ_SEED", "2025")) + 31)
+    trials = max(1, int(os.environ.get("PT_FUZZ_TRIALS", "40")) // 2)
+    n = 600
+    for trial in range(trials):
+        with _random_scene(gpu, rng, branching=False) as s:
+            scale = float(10 ** rng.uniform(-3, 4))
+            o = (rng.normal(0, 4, (n, 3)) * scale + np.array([0, 0, 4 * scale])).astype(f32)
+            o[: n // 4] = 0                                       # eye rays
+            d = rng.normal(size=(n, 3))
+            d /= np.linalg.norm(d, axis=1, keepdims=True)
+            d = d.astype(f32)
+            d[::7] *= f32(rng.uniform(0.5, 3))                   # not unit (glms_ray_sphere assumes it is)
+            kinds = rng.integers(0, 40, n)
+            d[kinds == 0] = 0
+            d[kinds == 1, 0] = np.nan
+            o[kinds == 2, 1] = np.inf
+            d[kinds == 3] *= f32(1e30)
+            o[kinds == 4] *= f32(1e20)
+            want = oracle.trace_rays(s, o, d)
+            hit = want[0] >= 0
+            scans = [A.FLAG_SCAN_PLAIN, A.FLAG_SCAN_SCREENED] + ([A.FLAG_SCAN_BVH] if s.num_objects >= 64 else [])
+            for scan in scans:
+                got = gpu.trace_rays(s, o, d, scan)
+                what = (trial, hex(scan), s.counts())
+
+                def same(a, b):
+                    # bit for bit, except that a NaN is a NaN: IEEE 754 leaves the sign and
+                    # payload of a generated NaN open, and inf - inf is 0xFFC00000 on the
+                    # host's SSE unit and 0x7FC00000 on the GPU (rays with an infinite origin)
+                    return bool(np.all((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))))
+
+                found = hit | np.isnan(want[0])          # a NaN distance is a found object too
+                assert same(got[0], want[0]), what
+                assert same(got[1][found], want[1][found]), what
+                assert same(got[2][found], want[2][found]), what
+                assert np.array_equal(got[3][found], want[3][found]), what
+
+
+def test_randomised_progressive_passes_compose_to_the_one_pass_frame(gpu, torch_cuda, oracle):
+    """A frame's samples split at random into accumulate passes, each pass with
+    its own schedule and scan form, on random scenes (branching ones too):
+    the resolved accumulator is the one-pass frame, and that is the oracle's."""
+    A = gpu._abi
+    torch = torch_cuda
+    stream = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(int(os.environ.get("PT_FUZZ_SEED", "2025")) + 47)
+    trials = max(1, int(os.environ.get("PT_FUZZ_TRIALS", "40")) // 2)
+    for trial in range(trials):
+        with _random_scene(gpu, rng, branching=bool(trial % 3 == 0)) as s, gpu.DeviceScene(s) as d:
+            w, h = int(rng.integers(8, 60)), int(rng.integers(5, 36))
+            spp = int(rng.integers(2, 9))
+            b = int(rng.integers(0, 6))
+            seed = int(rng.integers(0, 2 ** 31))
+            ref, _ = oracle.render_rows(s, w, h, spp=spp, max_bounces=b, seed=seed)
+            acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+            done = 0
+            while done < spp:
+                k = int(rng.integers(1, spp - done + 1))
+                f = int(rng.choice([A.FLAG_PIXEL_OWNER, A.FLAG_SAMPLE_QUEUE])) | \
+                    int(rng.choice([A.FLAG_SCAN_PLAIN, A.FLAG_SCAN_SCREENED] +
+                                   ([A.FLAG_SCAN_BVH] if s.num_objects >= 64 else [])))
+                d.accumulate(acc.data_ptr(), w, h, gpu.make_params(spp=k, sample_offset=done, max_bounces=b,
+                                                                    seed=seed, flags=f), stream)
+                done += k
+            out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+            gpu.host.resolve(acc.data_ptr(), out.data_ptr(), w * h, stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), ref), (trial, w, h, spp, b, seed, s.counts())
+
+
 def test_multi_device_gather_randomised(gpu, torch_cuda):
     """ptgpu_multi_render (peer-copy rehearsal on the one GPU) over random frame
     sizes, shard counts, tile heights, row sub-ranges and modes, against the
