@@ -986,10 +986,14 @@ def test_randomised_scenes_match_the_oracle(gpu, oracle, branching):
                 # resumable walks (+ LDS copy), queue with whole walks
                 flags = int(rng.choice([0x400, 0x480, 0x500, 0x540, 0xD00]))
             lanes = int(rng.choice([0, 0, 2, 8, 64])) if branching else 0
+            # field of view (the reference's is a macro, 90 degrees) and the first sample's index
+            fov = float(np.float32(rng.choice([np.pi / 2, np.pi / 2, 0.2, 1.0, 2.5, 3.0])))
+            first = int(rng.choice([0, 0, 1, 17, 100000]))
             got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=trial, flags=flags,
-                                   lanes_per_pixel=lanes)
-            ref, _ = oracle.render_rows(s, w, h, spp=spp, max_bounces=b, seed=trial)
-            assert np.array_equal(got, ref), (trial, w, h, spp, b, hex(flags), s.counts())
+                                   lanes_per_pixel=lanes, fov_rad=fov, sample_offset=first)
+            ref, _ = oracle.render_rows(s, w, h, spp=spp, max_bounces=b, seed=trial, fov_rad=fov,
+                                        sample_offset=first)
+            assert np.array_equal(got, ref), (trial, w, h, spp, b, hex(flags), fov, first, s.counts())
 
 
 def _scene_from_json(gpu, path):
