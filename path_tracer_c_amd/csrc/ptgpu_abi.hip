@@ -2426,9 +2426,16 @@ ray_hit trace_ray(const vec3s origin, const vec3s direction,
 // The pool shim (host/threadpool.c) hands over every row queued so far.
 void ptgpu_pool_render_rows(const render_args *queued, size_t n) {
     // group by (frame, size, scene); render each group's rows as contiguous runs
-    std::vector<const render_args *> rows(n);
-    for (size_t i = 0; i < n; i++)
-        rows[i] = queued + i;
+    // (a row outside its frame is dropped by itself -- the reference would write
+    // outside the buffer -- not together with the run of rows it sorts into)
+    std::vector<const render_args *> rows;
+    rows.reserve(n);
+    for (size_t i = 0; i < n; i++) {
+        const render_args &r = queued[i];
+        if (r.frame != nullptr && r.world != nullptr && r.screen_y >= 0 &&
+            (size_t)r.screen_y < r.frameh)
+            rows.push_back(&r);
+    }
     std::stable_sort(rows.begin(), rows.end(), [](const render_args *a, const render_args *b) {
         if (a->frame != b->frame) return a->frame < b->frame;
         if (a->world != b->world) return a->world < b->world;
@@ -2446,9 +2453,8 @@ void ptgpu_pool_render_rows(const render_args *queued, size_t n) {
                 rows[j]->screen_y == rows[j - 1]->screen_y + 1))
             ++j;
         const int y0 = head.screen_y, y1 = rows[j - 1]->screen_y;
-        if (head.frame && head.world && y0 >= 0 && (size_t)y1 < head.frameh)
-            legacy_render_rows(head.world, head.frame, head.framew, head.frameh, (uint32_t)y0,
-                               (uint32_t)(y1 - y0 + 1));
+        legacy_render_rows(head.world, head.frame, head.framew, head.frameh, (uint32_t)y0,
+                           (uint32_t)(y1 - y0 + 1));
         i = j;
     }
 }

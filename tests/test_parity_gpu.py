@@ -1272,6 +1272,66 @@ def test_threadpool_two_frames_two_scenes_and_foreign_tasks_in_one_wait(gpu, ora
         assert not f0.any()
 
 
+def test_threadpool_randomised_row_sets(gpu, oracle, monkeypatch):
+    """Random multisets of rows (duplicates, any order) of up to three frames of
+    different sizes and scenes, with ordinary tasks in between, queued on one
+    pool: after one wait every queued row is the oracle's and every other row
+    untouched; out-of-range rows are ignored (the reference would write outside
+    the frame)."""
+    monkeypatch.setenv("PTGPU_SPP", "2")
+    monkeypatch.setenv("PTGPU_BOUNCES", "3")
+    monkeypatch.setenv("PTGPU_SEED", "5")
+    A = gpu._abi
+    lib = gpu.lib()
+    task = C.cast(lib.render_task, C.c_void_p)
+    rng = np.random.default_rng(int(os.environ.get("PT_FUZZ_SEED", "2025")) + 61)
+    trials = max(2, int(os.environ.get("PT_FUZZ_TRIALS", "40")) // 8)
+    scenes = {k: gpu.HostScene(k) for k in (0, 1, 2)}
+    refs = {}
+    ran = []
+    cb = A.TASK_FN(lambda arg: ran.append(arg))
+    try:
+        for trial in range(trials):
+            frames = []
+            for _ in range(int(rng.integers(1, 4))):
+                k = int(rng.integers(0, 3))
+                w, h = int(rng.integers(4, 40)), int(rng.integers(1, 30))
+                if (k, w, h) not in refs:
+                    refs[(k, w, h)] = oracle.render_rows(scenes[k], w, h, spp=2, max_bounces=3, seed=5)[0]
+                frames.append((k, w, h, np.zeros((h, w, 3), dtype=np.uint8)))
+            jobs = []
+            for fi, (k, w, h, fr) in enumerate(frames):
+                rows = rng.integers(-2, h + 2, int(rng.integers(0, 2 * h + 1)))   # duplicates, a few out of range
+                jobs += [(fi, int(y)) for y in rows]
+            order = rng.permutation(len(jobs)) if jobs else []
+            args = (A.RenderArgs * max(1, len(jobs)))()
+            pool = A.ThreadPool()
+            lib.threadpool_init(C.byref(pool), int(rng.integers(0, 5)))
+            n_foreign = 0
+            before = len(ran)                       # (ordinary tasks start at once, on the pool's workers)
+            for n, j in enumerate(order):
+                fi, y = jobs[j]
+                k, w, h, fr = frames[fi]
+                args[n] = A.RenderArgs(y, w, h, fr.ctypes.data_as(C.POINTER(C.c_uint8)), C.pointer(scenes[k].c))
+                lib.threadpool_add_task(C.byref(pool), task, C.cast(C.byref(args[n]), C.c_void_p))
+                if rng.integers(5) == 0:
+                    lib.threadpool_add_task(C.byref(pool), C.cast(cb, C.c_void_p), C.c_void_p(n + 1))
+                    n_foreign += 1
+            lib.threadpool_wait_for_tasks(C.byref(pool))
+            assert len(ran) - before == n_foreign
+            lib.threadpool_destroy(C.byref(pool))
+            for fi, (k, w, h, fr) in enumerate(frames):
+                queued = {y for f, y in jobs if f == fi and 0 <= y < h}
+                for y in range(h):
+                    if y in queued:
+                        assert np.array_equal(fr[y], refs[(k, w, h)][y]), (trial, fi, y)
+                    else:
+                        assert not fr[y].any(), (trial, fi, y)
+    finally:
+        for sc in scenes.values():
+            sc.__exit__(None, None, None)
+
+
 def test_threadpool_runs_foreign_tasks_and_waits_for_all(gpu):
     """Ordinary tasks are run by the shim's own worker threads, as the
     reference's pool runs them: at once (no wait needed), several at a time."""
