@@ -264,7 +264,8 @@ int ptgpu_render_device(const ptgpu_scene *s, uint8_t *d_frame, size_t framew,
                         void *hip_stream);
 
 /* Synchronous convenience: upload, render, copy the rows back into the
- * caller's host frame (full-frame addressing), free. */
+ * caller's host frame, free.  Always full-frame addressing: row y of the row
+ * set lands at row y of `frame` (PTGPU_FLAG_COMPACT_ROWS has no effect here). */
 int ptgpu_render_frame(const scene *host_scene, uint8_t *frame, size_t framew,
                        size_t frameh, const ptgpu_params *p);
 

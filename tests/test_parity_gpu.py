@@ -2209,6 +2209,61 @@ def test_randomised_progressive_passes_compose_to_the_one_pass_frame(gpu, torch_
             assert np.array_equal(out.cpu().numpy(), ref), (trial, w, h, spp, b, seed, s.counts())
 
 
+def test_randomised_parameter_blocks_either_render_the_oracle_frame_or_are_refused(gpu, oracle):
+    """ptgpu_params drawn at random around every limit the header states --
+    row sets, tile strides, workgroup sizes, lanes per pixel, settle
+    thresholds, bounce limits, contradictory scheduling flags: a call either
+    returns an error code (and touches nothing) or renders exactly the rows it
+    was asked for, equal to the oracle's."""
+    A = gpu._abi
+    rng = np.random.default_rng(int(os.environ.get("PT_FUZZ_SEED", "2025")) + 83)
+    trials = int(os.environ.get("PT_FUZZ_TRIALS", "40"))
+    refs = {}
+    sched = [0, A.FLAG_PIXEL_OWNER, A.FLAG_SAMPLE_QUEUE, A.FLAG_PIXEL_OWNER | A.FLAG_SAMPLE_QUEUE]
+    scans = [0, A.FLAG_SCAN_PLAIN, A.FLAG_SCAN_SCREENED, A.FLAG_SCAN_BVH, A.FLAG_SCAN_PLAIN | A.FLAG_SCAN_BVH]
+    other = [0, A.FLAG_SCENE_LDS, A.FLAG_NO_PRIMARY_SHARE, A.FLAG_FORCE_TREE, A.FLAG_NO_RAY_COUNT, 0x800, A.FLAG_COMPACT_ROWS]
+    rendered = 0
+    with gpu.HostScene(2) as small, gpu.HostScene(5) as large:
+        for trial in range(trials):
+            s, sid = (large, 5) if trial % 3 == 0 else (small, 2)
+            w, h = int(rng.choice([1, 7, 33, 64])), int(rng.choice([1, 5, 24, 40]))
+            spp, b, seed = int(rng.choice([1, 1, 2, 3, 0])), int(rng.choice([0, 1, 4, 8, 14, 14, 15, 62, 63])), 11
+            if b > 14:
+                spp = min(spp, 1)                                  # (a 63-deep mirror path is not the point here)
+            def pick(valid, invalid):             # mostly a legal value, now and then one past a limit
+                return int(rng.choice(invalid if rng.integers(12) == 0 else valid))
+            row_begin = pick([0, 0, 1, h - 1], [h, h + 3])
+            left = h - min(row_begin, h - 1)
+            tile_rows = pick([0, 0, 0, 1, 2, 8], [0])
+            kw = dict(spp=spp, max_bounces=b, seed=seed, row_begin=row_begin,
+                      num_rows=pick([0, 1, left] if tile_rows == 0 else [1], [h + 1, 0 if tile_rows else h + 2]),
+                      tile_rows=tile_rows, tile_stride=pick([0, 1, 2, 5], [0]),
+                      block_threads=pick([0, 0, 64, 256, 1024], [100, 2048]),
+                      lanes_per_pixel=pick([0, 0, 1, 2, 16, 64], [3, 128]),
+                      settle_lanes=pick([0, 0, 1, 32, 64], [65]),
+                      flags=int(rng.choice(sched)) | int(rng.choice(scans)) | int(rng.choice(other)))
+            try:
+                got = gpu.render_frame(s, w, h, **kw)
+            except A.PtgpuError as e:
+                assert e.code in (A.PTGPU_ERR_INVALID, A.PTGPU_ERR_LIMIT), (trial, kw, e)
+                continue
+            key = (sid, w, h, spp, min(b, 62))
+            if key not in refs:
+                refs[key] = oracle.render_rows(s, w, h, spp=spp, max_bounces=b, seed=seed)[0]
+            # which rows did the call name?  (the documented row map)
+            p = gpu.make_params(**kw)
+            T, S = p.tile_rows, (p.tile_stride if p.tile_stride else 1)
+            n = p.num_rows if p.num_rows else h - p.row_begin
+            rows = [p.row_begin + i if T == 0 else p.row_begin + (i // T) * T * S + i % T for i in range(n)]
+            want = np.zeros_like(got)
+            for y in rows:                 # (the host-frame entry point addresses the full frame,
+                want[y] = refs[key][y]     #  PTGPU_FLAG_COMPACT_ROWS or not: include/ptgpu.h)
+            assert np.array_equal(got, want), f"trial {trial} scene {sid} {w}x{h} {kw} rows {rows[:6]}"
+            rendered += 1
+    assert rendered * 5 >= trials, (rendered, trials)        # the draw is not all refusals
+    print(f"{rendered} of {trials} parameter blocks rendered, the rest were refused")
+
+
 def test_multi_device_gather_randomised(gpu, torch_cuda):
     """ptgpu_multi_render (peer-copy rehearsal on the one GPU) over random frame
     sizes, shard counts, tile heights, row sub-ranges and modes, against the
