@@ -2132,6 +2132,32 @@ def test_trace_ray_with_a_direction_that_is_not_of_unit_length(gpu, oracle):
                 assert np.float32(hit.distance).view(np.uint32) == want[0][j].view(np.uint32)
 
 
+@pytest.mark.parametrize("cfg", [2, 5])
+def test_trace_rays_batch_sizes_around_the_wave_and_block_boundaries(gpu, oracle, cfg):
+    """pt_trace_kernel writes whole 40-byte hit records with staged 16-byte
+    stores when a wave is full and record by record otherwise: batches of 0,
+    1, 63, 64, 65 ... rays, every scan form, every hit field."""
+    A = gpu._abi
+    rng = np.random.default_rng(3)
+    with gpu.HostScene(cfg) as s:
+        scans = (0, A.FLAG_SCAN_PLAIN, A.FLAG_SCAN_SCREENED) + ((A.FLAG_SCAN_BVH,) if cfg == 5 else ())
+        for n in (0, 1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 4097):
+            o = rng.normal(0, 0.5, (n, 3)).astype(f32)
+            d = rng.normal(size=(n, 3))
+            d = (d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-9)).astype(f32)
+            want = oracle.trace_rays(s, o, d) if n else None
+            for scan in scans:
+                got = gpu.trace_rays(s, o, d, scan)
+                assert len(got[0]) == n
+                if n == 0:
+                    continue
+                hit = want[0] >= 0
+                assert np.array_equal(bits(got[0]), bits(want[0])), (n, hex(scan))
+                assert np.array_equal(bits(got[1][hit]), bits(want[1][hit])), (n, hex(scan))
+                assert np.array_equal(bits(got[2][hit]), bits(want[2][hit])), (n, hex(scan))
+                assert np.array_equal(got[3][hit], want[3][hit]), (n, hex(scan))
+
+
 def test_randomised_rays_through_randomised_scenes_in_every_scan_form(gpu, oracle):
     """ptgpu_trace_rays on the fuzz generator's hostile scenes with rays of
     every kind a render produces and some it does not: from inside and
