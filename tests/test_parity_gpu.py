@@ -2219,20 +2219,30 @@ def test_randomised_progressive_passes_compose_to_the_one_pass_frame(gpu, torch_
             b = int(rng.integers(0, 6))
             seed = int(rng.integers(0, 2 ** 31))
             ref, _ = oracle.render_rows(s, w, h, spp=spp, max_bounces=b, seed=seed)
+            # the row set: the whole frame, or a run of rows, addressed in place or compactly
+            y0 = int(rng.integers(0, h)) if trial % 2 else 0
+            n = int(rng.integers(1, h - y0 + 1)) if trial % 2 else h
+            compact = A.FLAG_COMPACT_ROWS if (trial % 4 == 1) else 0
             acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
             done = 0
             while done < spp:
                 k = int(rng.integers(1, spp - done + 1))
-                f = int(rng.choice([A.FLAG_PIXEL_OWNER, A.FLAG_SAMPLE_QUEUE])) | \
+                f = int(rng.choice([A.FLAG_PIXEL_OWNER, A.FLAG_SAMPLE_QUEUE])) | compact | \
                     int(rng.choice([A.FLAG_SCAN_PLAIN, A.FLAG_SCAN_SCREENED] +
                                    ([A.FLAG_SCAN_BVH] if s.num_objects >= 64 else [])))
                 d.accumulate(acc.data_ptr(), w, h, gpu.make_params(spp=k, sample_offset=done, max_bounces=b,
-                                                                    seed=seed, flags=f), stream)
+                                                                    seed=seed, flags=f, row_begin=y0, num_rows=n), stream)
                 done += k
             out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
             gpu.host.resolve(acc.data_ptr(), out.data_ptr(), w * h, stream)
             torch.cuda.synchronize()
-            assert np.array_equal(out.cpu().numpy(), ref), (trial, w, h, spp, b, seed, s.counts())
+            got = out.cpu().numpy()
+            at = 0 if compact else y0
+            assert np.array_equal(got[at:at + n], ref[y0:y0 + n]), (trial, w, h, spp, b, seed, y0, n, compact, s.counts())
+            sums = acc.cpu().numpy()
+            outside = np.ones(h, dtype=bool)
+            outside[at:at + n] = False
+            assert not sums[outside].any(), (trial, y0, n, compact)     # rows not named stay untouched
 
 
 def test_randomised_parameter_blocks_either_render_the_oracle_frame_or_are_refused(gpu, oracle):
