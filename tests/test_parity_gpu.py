@@ -2211,7 +2211,7 @@ def test_randomised_progressive_passes_compose_to_the_one_pass_frame(gpu, torch_
     torch = torch_cuda
     stream = torch.cuda.current_stream().cuda_stream
     rng = np.random.default_rng(int(os.environ.get("PT_FUZZ_SEED", "2025")) + 47)
-    trials = max(1, int(os.environ.get("PT_FUZZ_TRIALS", "40")) // 2)
+    trials = max(5, int(os.environ.get("PT_FUZZ_TRIALS", "40")) // 8)   # (0.1 s per trial)
     for trial in range(trials):
         with _random_scene(gpu, rng, branching=bool(trial % 3 == 0)) as s, gpu.DeviceScene(s) as d:
             w, h = int(rng.integers(8, 60)), int(rng.integers(5, 36))
