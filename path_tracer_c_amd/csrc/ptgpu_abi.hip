@@ -303,9 +303,13 @@ static bool env_u32(const char *name, uint32_t *out) {
     const char *v = std::getenv(name);
     if (v == nullptr || *v == '\0')
         return false;
+    while (*v == ' ' || *v == '\t')
+        ++v;
+    if (*v == '-') // strtoull would wrap "-1" to 2^64 - 1: not a setting anybody meant
+        return false;
     char *end = nullptr;
     unsigned long long x = std::strtoull(v, &end, 0);
-    if (end == v)
+    if (end == v || x > 0xFFFFFFFFull)
         return false;
     *out = (uint32_t)x;
     return true;

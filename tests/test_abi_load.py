@@ -74,6 +74,25 @@ def test_params_from_env(pt, monkeypatch):
     assert abs(p.fov_rad - 1.0471976) < 1e-6
 
 
+def test_env_values_nobody_meant_are_ignored(pt, monkeypatch):
+    """A negative number would wrap to 4 billion samples per pixel, a value
+    beyond 32 bits would be cut to its low word: both, like text and the empty
+    string, leave the reference's defaults in place."""
+    for bad in ("-1", " -7", "99999999999", "abc", "", "  "):
+        monkeypatch.setenv("PTGPU_SPP", bad)
+        monkeypatch.setenv("PTGPU_BOUNCES", bad)
+        p = pt._abi.Params()
+        assert pt.lib().ptgpu_params_from_env(C.byref(p)) == 0
+        assert (p.spp, p.max_bounces) == (16, 4), bad
+    monkeypatch.setenv("PTGPU_SPP", " 12")
+    monkeypatch.setenv("PTGPU_BOUNCES", "4294967295")
+    monkeypatch.setenv("PTGPU_FOV_DEG", "-30")
+    p = pt._abi.Params()
+    assert pt.lib().ptgpu_params_from_env(C.byref(p)) == 0
+    assert (p.spp, p.max_bounces) == (12, 4294967295)
+    assert abs(p.fov_rad - 1.5707964) < 1e-7           # an angle outside (0, 180) is ignored too
+
+
 def test_null_arguments_are_rejected_not_crashed(pt):
     lib = pt.lib()
     assert lib.ptgpu_params_default(None) == pt._abi.PTGPU_ERR_INVALID
