@@ -233,6 +233,11 @@ int main(int argc, char **argv) {
     size_t width = argc > 2 ? (size_t)atol(argv[2]) : WIDTH;
     size_t height = argc > 3 ? (size_t)atol(argv[3]) : HEIGHT;
     char *path = argc > 4 ? argv[4] : "output.bmp";
+    if ((argc > 2 && atol(argv[2]) <= 0) || (argc > 3 && atol(argv[3]) <= 0) ||
+        width > 1048560 || height > 1048560) { /* the library's own limit: 65535 * 16 */
+        fprintf(stderr, "usage: %s [config 0..5] [width] [height] [out.bmp]  (sizes 1..1048560)\n", argv[0]);
+        return 2;
+    }
 
     scene world;
     if (ptgpu_build_config_scene(config, &world) != PTGPU_OK) {

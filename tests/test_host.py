@@ -109,3 +109,20 @@ def test_config_scenes(pt):
     # deterministic: two builds give the same bytes
     with pt.HostScene(5) as a, pt.HostScene(5) as b:
         assert C.string_at(a.c.objects, 56 * 1001) == C.string_at(b.c.objects, 56 * 1001)
+
+
+def test_driver_refuses_frame_sizes_nobody_meant(pt):
+    """bin/ptrender (csrc/host/main.c): a negative, zero or absurd size is a
+    usage error (status 2) before anything touches the GPU -- atol() of "-5"
+    cast to size_t would otherwise be an 18-digit width."""
+    import subprocess
+    from pathlib import Path
+    exe = Path(__file__).resolve().parent.parent / "bin" / "ptrender"
+    if not exe.exists():
+        import pytest
+        pytest.skip("bin/ptrender is not built")
+    for args in (["2", "-5", "10"], ["2", "10", "0"], ["2", "99999999", "4"]):
+        run = subprocess.run([str(exe), *args, "/dev/null"], capture_output=True, text=True, timeout=60)
+        assert run.returncode == 2 and "usage" in run.stderr, (args, run.returncode, run.stderr)
+    run = subprocess.run([str(exe), "99"], capture_output=True, text=True, timeout=60)
+    assert run.returncode == 1 and "unknown scene configuration" in run.stderr
