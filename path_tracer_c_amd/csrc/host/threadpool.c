@@ -72,6 +72,8 @@ static void *worker_main(void *arg) {
     pthread_mutex_lock(&pool->tasks_mutex);
     pool_head *head = head_of(pool);
     for (;;) {
+        if (head == NULL) // (cannot be: workers are started by an initialised pool)
+            break;
         while (pool->threads_running && head->foreign.size == 0)
             pthread_cond_wait(&pool->tasks_available_cond, &pool->tasks_mutex);
         if (!pool->threads_running)
@@ -132,9 +134,13 @@ void threadpool_add_task(threadpool *pool, void (*f)(void *), void *arg) {
         vector_push(&pool->tasks, task);
     } else {
         pool_head *head = head_of(pool);
-        vector_push(&head->foreign, task);
-        start_workers_as_needed(pool, head);
-        pthread_cond_signal(&pool->tasks_available_cond);
+        if (head == NULL) { // a pool that was never initialised (or already destroyed)
+            free(task);
+        } else {
+            vector_push(&head->foreign, task);
+            start_workers_as_needed(pool, head);
+            pthread_cond_signal(&pool->tasks_available_cond);
+        }
     }
     pthread_mutex_unlock(&pool->tasks_mutex);
 }
@@ -161,6 +167,10 @@ void threadpool_wait_for_tasks(threadpool *pool) {
         // run here, newest first.)
         pthread_mutex_lock(&pool->tasks_mutex);
         pool_head *head = head_of(pool);
+        if (head == NULL) { // never initialised: nothing can be queued
+            pthread_mutex_unlock(&pool->tasks_mutex);
+            return;
+        }
         while (head->started == 0 && head->foreign.size != 0) {
             pool_task *t = (pool_task *)vector_pop(&head->foreign);
             pthread_mutex_unlock(&pool->tasks_mutex);
