@@ -472,21 +472,21 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
         // bounding sphere the screen uses); spheres: none (lo > hi)
         std::vector<float> corners((size_t)6 * n_obj);
         for (uint32_t i = 0; i < n_obj; ++i) {
-            float *e = &corners[(size_t)6 * i];
-            e[0] = 1.0f;
-            e[3] = 0.0f;
+            float *ext = &corners[(size_t)6 * i];
+            ext[0] = 1.0f;
+            ext[3] = 0.0f;
             const shape &o = host->objects[i];
             if (o.tag != 1)
                 continue;
             const vec3s v[3] = {o.triangle.v0, o.triangle.v1, o.triangle.v2};
             for (int ax = 0; ax < 3; ++ax) {
                 const float x0 = v[0].raw[ax], x1 = v[1].raw[ax], x2 = v[2].raw[ax];
-                e[ax] = std::min(x0, std::min(x1, x2));
-                e[ax + 3] = std::max(x0, std::max(x1, x2));
+                ext[ax] = std::min(x0, std::min(x1, x2));
+                ext[ax + 3] = std::max(x0, std::max(x1, x2));
             }
-            if (!(e[0] <= e[3])) { // NaN vertex: no extent of its own
-                e[0] = 1.0f;
-                e[3] = 0.0f;
+            if (!(ext[0] <= ext[3])) { // NaN vertex: no extent of its own
+                ext[0] = 1.0f;
+                ext[3] = 0.0f;
             }
         }
         const pt::BvhHost bvh = pt::build_bvh(geom, n_obj, corners.data());
