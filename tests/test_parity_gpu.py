@@ -2077,10 +2077,11 @@ def test_glsl_semantics_randomised_scenes_match_the_shader_oracle(gpu, oracle):
             spp = int(rng.integers(1, 4))
             b = int(rng.integers(0, 7))
             seed = int(rng.integers(0, 2**31))
-            got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=seed,
+            fov = float(np.float32(rng.choice([np.pi / 2, np.pi / 2, 0.3, 1.2, 2.8])))
+            got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=seed, fov_rad=fov,
                                    flags=gpu._abi.FLAG_GLSL_SEMANTICS)
-            ref = oracle.glsl_render_rows(s, w, h, spp=spp, max_bounces=b, seed=seed)[0]
-            assert np.array_equal(got, ref), (trial, w, h, spp, b, seed, s.counts())
+            ref = oracle.glsl_render_rows(s, w, h, spp=spp, max_bounces=b, seed=seed, fov_rad=fov)[0]
+            assert np.array_equal(got, ref), (trial, w, h, spp, b, seed, fov, s.counts())
 
 
 def test_fast_math_randomised_scenes_are_the_same_picture_in_every_scan_form(gpu):
