@@ -2353,7 +2353,17 @@ def test_direct_render_task_randomised_call_orders(gpu, oracle, monkeypatch):
                 elif move == 9 and rng.integers(4) == 0:       # edit the scene: later rows are the new scene's
                     s.c.objects[0].sphere.radius *= 1.05
                     ref, _ = oracle.render_rows(s, w, h, spp=3, max_bounces=4, seed=seed)
+                elif move == 9 and rng.integers(3) == 0:       # or the settings: a new seed, or only the
+                    if rng.integers(2):                        # schedule (same picture, the cache may stay)
+                        seed = int(rng.integers(1, 1000))
+                        monkeypatch.setenv("PTGPU_SEED", str(seed))
+                        ref, _ = oracle.render_rows(s, w, h, spp=3, max_bounces=4, seed=seed)
+                    else:
+                        monkeypatch.setenv("PTGPU_FLAGS", str(int(rng.choice([0, 0x80, 0x100, 0x10, 0x20]))))
+                        monkeypatch.setenv("PTGPU_LANES_PER_PIXEL", str(int(rng.choice([0, 2, 16]))))
                 _direct_rows(gpu, s, w, h, [y], frame=frame)
                 want[y] = ref[y]
                 assert np.array_equal(frame[y], want[y]), (trial, y)
             assert np.array_equal(frame, want)
+    monkeypatch.delenv("PTGPU_FLAGS", raising=False)
+    monkeypatch.delenv("PTGPU_LANES_PER_PIXEL", raising=False)
