@@ -1207,6 +1207,77 @@ def test_host_threads_render_concurrently(gpu, oracle):
     assert not errors, errors
 
 
+def test_host_threads_random_mix_of_calls(gpu, oracle, monkeypatch):
+    """Four host threads, each a random sequence of the library's host-buffer
+    calls -- frames in random schedules and scan forms, ray batches, the legacy
+    pool path, direct render_task rows, ptgpu_release_scratch in between --
+    on shared and on private scenes.  Every result is checked; a deadlock shows
+    as the test's timeout."""
+    import threading
+    monkeypatch.setenv("PTGPU_SPP", "3")
+    monkeypatch.setenv("PTGPU_BOUNCES", "4")
+    monkeypatch.setenv("PTGPU_SEED", "9")
+    A = gpu._abi
+    lib = gpu.lib()
+    rounds = max(20, int(os.environ.get("PT_FUZZ_TRIALS", "40")))
+    scenes = [gpu.HostScene(k) for k in (0, 1, 2, 5)]
+    sizes = [(40, 24), (33, 17), (48, 27), (32, 18)]
+    frames = [oracle.render_rows(s, w, h, spp=3, max_bounces=4, seed=9)[0] for s, (w, h) in zip(scenes, sizes)]
+    rng0 = np.random.default_rng(3)
+    rays_o = rng0.normal(0, 1, (500, 3)).astype(f32)
+    rays_d = rng0.normal(size=(500, 3))
+    rays_d = (rays_d / np.linalg.norm(rays_d, axis=1, keepdims=True)).astype(f32)
+    hits = [oracle.trace_rays(s, rays_o, rays_d) for s in scenes]
+    errors = []
+
+    def worker(t):
+        rng = np.random.default_rng(100 + t)
+        try:
+            for it in range(rounds):
+                k = int(rng.integers(len(scenes)))
+                s, (w, h) = scenes[k], sizes[k]
+                op = int(rng.integers(6))
+                if op == 0:
+                    f = int(rng.choice([0, A.FLAG_PIXEL_OWNER, A.FLAG_SAMPLE_QUEUE])) | \
+                        int(rng.choice([0, A.FLAG_SCAN_PLAIN, A.FLAG_SCAN_SCREENED]))
+                    got = gpu.render_frame(s, w, h, spp=3, max_bounces=4, seed=9, flags=f)
+                    ok = np.array_equal(got, frames[k])
+                elif op == 1:
+                    got = gpu.trace_rays(s, rays_o, rays_d, int(rng.choice([0, A.FLAG_SCAN_PLAIN, A.FLAG_SCAN_SCREENED])))
+                    ok = np.array_equal(bits(got[0]), bits(hits[k][0]))
+                elif op == 2:
+                    got = gpu.host.render_frame_legacy(s, w, h)
+                    ok = np.array_equal(got, frames[k])
+                elif op == 3:
+                    rows = [int(y) for y in rng.integers(0, h, 5)]
+                    fr = np.zeros((h, w, 3), dtype=np.uint8)
+                    _direct_rows(gpu, s, w, h, rows, frame=fr)
+                    ok = all(np.array_equal(fr[y], frames[k][y]) for y in rows)
+                elif op == 4:
+                    lib.ptgpu_release_scratch()
+                    ok = True
+                else:
+                    with gpu.HostScene(k if k != 3 else 5) as own:       # a private copy of the same content
+                        got = gpu.render_frame(own, w, h, spp=3, max_bounces=4, seed=9,
+                                               flags=int(rng.choice([0, A.FLAG_SAMPLE_QUEUE])))
+                    ok = np.array_equal(got, frames[k])
+                if not ok:
+                    errors.append(f"thread {t} iteration {it}: op {op} on scene {k} differs")
+                    return
+        except Exception as exc:                          # pragma: no cover
+            errors.append(f"thread {t}: {exc!r}")
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+        assert not t.is_alive(), "a host thread is stuck (deadlock?)"
+    for s in scenes:
+        s.close()
+    assert not errors, errors
+
+
 # ---- the legacy call sequence (threadpool + render_task) -----------------------------------
 def test_threadpool_render_task_frame(gpu, oracle, monkeypatch):
     monkeypatch.setenv("PTGPU_SPP", "8")
