@@ -100,13 +100,17 @@ static void build_cornell(scene *w) {
 }
 
 /* Scene-generation stream: xorshift32 seeded with 42, 24-bit uniform floats.
- * (Independent of the render stream in ptgpu_rng.h.) */
-static uint32_t gen_state;
-static double gen_uniform(double lo, double hi) {
-    gen_state ^= gen_state << 13;
-    gen_state ^= gen_state >> 17;
-    gen_state ^= gen_state << 5;
-    double u = (double)(gen_state >> 8) / 16777216.0;
+ * (Independent of the render stream in ptgpu_rng.h.)
+ * The state is the caller's: two threads may build configuration 5 at the
+ * same time (a file-level state let them scramble each other's scene -- found
+ * by the host-thread stress test of round 2). */
+static double gen_uniform_from(uint32_t *state, double lo, double hi) {
+    uint32_t x = *state;
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    *state = x;
+    double u = (double)(x >> 8) / 16777216.0;
     return lo + (hi - lo) * u;
 }
 
@@ -116,7 +120,8 @@ static void build_c5(scene *w) {
      * uniform over 16; overlapping spheres are NOT rejected.  A ground sphere
      * is object 1001.  The 16 materials: 10 matte colours, 2 lamps, 2
      * mirrors, 2 glasses. */
-    gen_state = 42u;
+    uint32_t gen_state = 42u;
+#define gen_uniform(lo, hi) gen_uniform_from(&gen_state, (lo), (hi))
     w->sky_color = v3(135.0 / 255.0, 206.0 / 255.0, 235.0 / 255.0);
     size_t first = 0;
     for (int i = 0; i < 16; i++) {
@@ -147,6 +152,7 @@ static void build_c5(scene *w) {
     }
     size_t ground = matte(w, 0.45, 0.5, 0.4, 1.0);
     scene_add_sphere(w, v3(0.0, -1001.8, 30.0), 1000.0f, ground);
+#undef gen_uniform
 }
 
 int ptgpu_build_config_scene(int config, scene *out) {
