@@ -1278,6 +1278,95 @@ def test_host_threads_random_mix_of_calls(gpu, oracle, monkeypatch):
     assert not errors, errors
 
 
+def test_host_threads_random_mix_of_device_calls_on_shared_scenes(gpu, torch_cuda, oracle):
+    """Four host threads, each with a HIP stream of its own, share four
+    device-resident scenes and issue a random mix of the asynchronous calls --
+    frames in either schedule, accumulate passes + resolve, ray batches -- plus
+    uploads and frees of private scenes.  The per-device scratch (sample
+    buffer, accumulator, primary-hit table, chunk counters) is what they
+    contend for; every result is checked after its stream has drained."""
+    import threading
+    torch = torch_cuda
+    A = gpu._abi
+    rounds = max(20, int(os.environ.get("PT_FUZZ_TRIALS", "40")))
+    cfgs = (0, 1, 2, 5)
+    sizes = [(40, 24), (33, 17), (48, 27), (64, 36)]
+    hosts = [gpu.HostScene(k) for k in cfgs]
+    devs = [gpu.DeviceScene(s) for s in hosts]
+    kw = dict(spp=4, max_bounces=4, seed=21)
+    frames = [oracle.render_rows(s, w, h, **kw)[0] for s, (w, h) in zip(hosts, sizes)]
+    rng0 = np.random.default_rng(5)
+    n_rays = 777
+    rays_o = rng0.normal(0, 1, (n_rays, 3)).astype(f32)
+    rays_d = rng0.normal(size=(n_rays, 3))
+    rays_d = (rays_d / np.linalg.norm(rays_d, axis=1, keepdims=True)).astype(f32)
+    hits = [oracle.trace_rays(s, rays_o, rays_d)[0] for s in hosts]
+    errors = []
+
+    def worker(t):
+        rng = np.random.default_rng(200 + t)
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                d_o = torch.from_numpy(rays_o).cuda()
+                d_d = torch.from_numpy(rays_d).cuda()
+                d_hits = torch.empty((n_rays, 10), dtype=torch.float32, device="cuda")
+            stream.synchronize()
+            for it in range(rounds):
+                k = int(rng.integers(len(devs)))
+                (w, h), d = sizes[k], devs[k]
+                op = int(rng.integers(5))
+                own = None
+                if op == 4:                                    # a private upload of the same content
+                    own = gpu.DeviceScene(hosts[k])
+                    d = own
+                    op = int(rng.integers(2))
+                f = int(rng.choice([A.FLAG_PIXEL_OWNER, A.FLAG_SAMPLE_QUEUE, 0]))
+                with torch.cuda.stream(stream):
+                    if op == 0:
+                        out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+                        d.render(out.data_ptr(), w, h, gpu.make_params(flags=f, **kw), stream.cuda_stream)
+                    elif op == 1:
+                        acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+                        out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+                        d.accumulate(acc.data_ptr(), w, h, gpu.make_params(spp=1, max_bounces=4, seed=21, flags=f),
+                                     stream.cuda_stream)
+                        d.accumulate(acc.data_ptr(), w, h, gpu.make_params(spp=3, sample_offset=1, max_bounces=4,
+                                                                            seed=21, flags=f ^ A.FLAG_SAMPLE_QUEUE if f else 0),
+                                     stream.cuda_stream)
+                        gpu.host.resolve(acc.data_ptr(), out.data_ptr(), w * h, stream.cuda_stream)
+                    elif op == 2:
+                        d.trace(d_o.data_ptr(), d_d.data_ptr(), n_rays, d_hits.data_ptr(),
+                                int(rng.choice([0, A.FLAG_SCAN_PLAIN, A.FLAG_SCAN_SCREENED])), stream.cuda_stream)
+                    else:
+                        out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+                        d.render(out.data_ptr(), w, h, gpu.make_params(flags=f | A.FLAG_SCAN_PLAIN, **kw), stream.cuda_stream)
+                stream.synchronize()
+                if op == 2:
+                    ok = np.array_equal(bits(d_hits[:, 0].cpu().numpy()), bits(hits[k]))
+                else:
+                    ok = np.array_equal(out.cpu().numpy(), frames[k])
+                if own is not None:
+                    own.close()
+                if not ok:
+                    errors.append(f"thread {t} iteration {it}: op {op} on scene {k} (flags {f:#x}) differs")
+                    return
+        except Exception as exc:                          # pragma: no cover
+            errors.append(f"thread {t}: {exc!r}")
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+        assert not t.is_alive(), "a host thread is stuck (deadlock?)"
+    for d in devs:
+        d.close()
+    for s in hosts:
+        s.close()
+    assert not errors, errors
+
+
 # ---- the legacy call sequence (threadpool + render_task) -----------------------------------
 def test_threadpool_render_task_frame(gpu, oracle, monkeypatch):
     monkeypatch.setenv("PTGPU_SPP", "8")
