@@ -69,7 +69,7 @@ clean:
 	rm -rf $(BUILD) $(LIBDIR) bin
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean asan-driver
+.PHONY: all oracle clean asan-driver tsan-driver
 
 # Host-side AddressSanitizer + UBSan build of the C driver with the library
 # linked in statically: the C-ABI translation unit (all host logic: upload, BVH
@@ -91,3 +91,20 @@ asan-driver: | $(BUILD) bin
 	$(HIPCC) --offload-arch=$(ARCH) -fno-gpu-sanitize -fsanitize=address,undefined -o bin/ptrender_asan \
 	  $(BUILD)/asan_main.o $(BUILD)/asan_threadpool.o $(BUILD)/asan_scene.o $(BUILD)/asan_vector.o $(BUILD)/asan_bitmap.o $(BUILD)/asan_scenes.o \
 	  $(BUILD)/asan_abi.o $(BUILD)/asan_kernels.o $(BUILD)/asan_kernels_fast.o $(BUILD)/asan_glsl.o -lpthread -lm
+
+# Host-side ThreadSanitizer build: the C-ABI translation unit and the host C
+# instrumented, the kernels plain, linked with a four-thread stress driver
+# (tests/c/thread_stress.c).  Run on a GPU box: tools/tsan_driver.sh
+TSAN_HOST := -Xarch_host -fsanitize=thread -Xarch_host -fno-omit-frame-pointer
+tsan-driver: | $(BUILD) bin
+	$(HIPCC) $(filter-out -O3,$(HIPFLAGS)) -O1 -g $(TSAN_HOST) -c $(CSRC)/ptgpu_abi.hip -o $(BUILD)/tsan_abi.o
+	$(HIPCC) $(filter-out -O3,$(HIPFLAGS)) -O1 -g -c $(CSRC)/device/pt_kernels.hip -o $(BUILD)/tsan_kernels.o
+	$(HIPCC) $(filter-out -O3,$(FASTFLAGS)) -O1 -g -c $(CSRC)/device/pt_kernels.hip -o $(BUILD)/tsan_kernels_fast.o
+	$(HIPCC) $(filter-out -O3,$(HIPFLAGS)) -O1 -g -c $(CSRC)/device/pt_glsl.hip -o $(BUILD)/tsan_glsl.o
+	for f in scene vector bitmap scenes threadpool; do \
+	  $(CLANG) -std=gnu2x -O1 -g -fsanitize=thread -fno-omit-frame-pointer -ffp-contract=off -Iinclude -I$(CSRC)/host \
+	    -c $(CSRC)/host/$$f.c -o $(BUILD)/tsan_$$f.o || exit 1; done
+	$(CLANG) -std=gnu2x -O1 -g -fsanitize=thread -fno-omit-frame-pointer -Iinclude -c tests/c/thread_stress.c -o $(BUILD)/tsan_stress.o
+	$(HIPCC) --offload-arch=$(ARCH) -fno-gpu-sanitize -fsanitize=thread -o bin/thread_stress_tsan \
+	  $(BUILD)/tsan_stress.o $(BUILD)/tsan_threadpool.o $(BUILD)/tsan_scene.o $(BUILD)/tsan_vector.o $(BUILD)/tsan_bitmap.o $(BUILD)/tsan_scenes.o \
+	  $(BUILD)/tsan_abi.o $(BUILD)/tsan_kernels.o $(BUILD)/tsan_kernels_fast.o $(BUILD)/tsan_glsl.o -lpthread -lm

@@ -879,6 +879,23 @@ def test_host_code_under_sanitizers_with_real_kernels(gpu, tmp_path):
     assert pixels.mean() > 10                      # a real frame, not a black one
 
 
+def test_host_code_under_thread_sanitizer_with_four_threads_of_mixed_calls(gpu, tmp_path):
+    """bin/thread_stress_tsan (make tsan-driver, built by __graft_entry__.build()):
+    tests/c/thread_stress.c linked with the C-ABI translation unit and the
+    host C under ThreadSanitizer, device code plain.  Four threads, a fixed
+    random mix of host-frame renders on shared and private scenes, the legacy
+    pool, direct render_task rows, ray batches, uploads, statistics and
+    ptgpu_release_scratch: every frame as expected and no race report."""
+    root = Path(__file__).resolve().parent.parent
+    exe = root / "bin" / "thread_stress_tsan"
+    assert exe.exists(), "bin/thread_stress_tsan missing: run `make tsan-driver` (build() does)"
+    run = subprocess.run(["bash", str(root / "tools" / "tsan_driver.sh"), str(tmp_path), "400"],
+                         cwd=root, capture_output=True, text=True, timeout=600)
+    log = (tmp_path / "thread_stress.log").read_text()
+    assert "thread_stress: ok (4 threads x 400 calls)" in log, log[-3000:]
+    assert "ThreadSanitizer" not in log, log[-6000:]
+
+
 def test_primary_hits_are_shared_in_the_stream_kernel_and_accounted(gpu, oracle):
     """Sample queue + BVH scan: every task starts at its pixel's primary hit,
     found once per call (pt_primary_kernel).  Same frame; `rays` still counts
