@@ -1332,8 +1332,19 @@ def test_host_threads_random_mix_of_device_calls_on_shared_scenes(gpu, torch_cud
             for it in range(rounds):
                 k = int(rng.integers(len(devs)))
                 (w, h), d = sizes[k], devs[k]
-                op = int(rng.integers(5))
+                op = int(rng.integers(6))
                 own = None
+                if op == 5:                                    # the one-process multi-device path, three shards
+                    with gpu.host.MultiDevice([0, 0, 0], peer_copy=True) as m:       # on this one GPU, its own streams
+                        m.upload(hosts[k])
+                        out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+                        torch.cuda.synchronize()
+                        m.render(out.data_ptr(), w, h, gpu.make_params(
+                            flags=int(rng.choice([0, A.FLAG_SAMPLE_QUEUE])), **kw), int(rng.choice([0, 1, 5])))
+                    if not np.array_equal(out.cpu().numpy(), frames[k]):
+                        errors.append(f"thread {t} iteration {it}: multi-device frame of scene {k} differs")
+                        return
+                    continue
                 if op == 4:                                    # a private upload of the same content
                     own = gpu.DeviceScene(hosts[k])
                     d = own
