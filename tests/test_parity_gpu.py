@@ -805,6 +805,41 @@ def test_progressive_driver_resumes_to_the_same_picture(gpu, tmp_path):
     assert np.array_equal(_bmp_pixels(out, w, h), ref)
 
 
+def test_progressive_driver_randomised_stops_and_resumes(gpu, tmp_path):
+    """bin/ptrender's progressive mode interrupted at random points, any number
+    of times, with random samples per pass (not always a divisor of the total),
+    on random configurations: the final picture is that of one uninterrupted
+    render, and a snapshot is refused by a run with other settings."""
+    import subprocess
+    exe = Path(__file__).resolve().parent.parent / "bin" / "ptrender"
+    rng = np.random.default_rng(int(os.environ.get("PT_FUZZ_SEED", "2025")) + 71)
+    for trial in range(max(3, int(os.environ.get("PT_FUZZ_TRIALS", "40")) // 10)):
+        cfg = int(rng.choice([0, 1, 2]))
+        w, h = int(rng.integers(8, 60)), int(rng.integers(6, 40))
+        total, per = int(rng.integers(2, 24)), int(rng.integers(1, 9))
+        seed = int(rng.integers(1, 999))
+        base = dict(os.environ, PTGPU_SPP=str(total), PTGPU_BOUNCES="4", PTGPU_SEED=str(seed),
+                    PTGPU_PROGRESSIVE=str(per))
+        out, acc = tmp_path / f"r{trial}.bmp", tmp_path / f"r{trial}.acc"
+        run = lambda env: subprocess.run([str(exe), str(cfg), str(w), str(h), str(out)], env=env,
+                                         capture_output=True, text=True, timeout=120)
+        done = 0
+        for _ in range(int(rng.integers(0, 4))):                 # interrupted runs
+            stop = int(rng.integers(done, total + 1))
+            r = run(dict(base, PTGPU_RESUME=str(acc), PTGPU_STOP_AFTER=str(stop)))
+            assert r.returncode == 0, (trial, r.stdout, r.stderr)
+            done = max(done, min(total, -(-stop // per) * per if stop > done else done))
+        if done and rng.integers(3) == 0:                        # somebody else's settings: refused
+            r = run(dict(base, PTGPU_RESUME=str(acc), PTGPU_SEED=str(seed + 1)))
+            assert r.returncode != 0 and "refusing" in r.stderr, (trial, r.stdout, r.stderr)
+        r = run(dict(base, PTGPU_RESUME=str(acc)))
+        assert r.returncode == 0 and (f"{total}/{total} spp" in r.stdout or          # the last pass ran now,
+                                      f"at {total} of {total} spp" in r.stdout), (trial, r.stdout, r.stderr)  # or before
+        with gpu.HostScene(cfg) as s:
+            ref = gpu.render_frame(s, w, h, spp=total, max_bounces=4, seed=seed)
+        assert np.array_equal(_bmp_pixels(out, w, h), ref), (trial, cfg, w, h, total, per)
+
+
 @pytest.mark.parametrize("n_dev,tile", [(2, 8), (3, 5), (4, 0)])
 def test_single_process_multi_device_frame(gpu, n_dev, tile):
     """ptgpu_render_frame_multi deals interleaved row tiles to a device list
