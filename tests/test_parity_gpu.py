@@ -813,7 +813,7 @@ def test_progressive_driver_randomised_stops_and_resumes(gpu, tmp_path):
     import subprocess
     exe = Path(__file__).resolve().parent.parent / "bin" / "ptrender"
     rng = np.random.default_rng(int(os.environ.get("PT_FUZZ_SEED", "2025")) + 71)
-    for trial in range(max(3, int(os.environ.get("PT_FUZZ_TRIALS", "40")) // 10)):
+    for trial in range(min(60, max(3, int(os.environ.get("PT_FUZZ_TRIALS", "40")) // 10))):   # (~1 s per trial)
         cfg = int(rng.choice([0, 1, 2]))
         w, h = int(rng.integers(8, 60)), int(rng.integers(6, 40))
         total, per = int(rng.integers(2, 24)), int(rng.integers(1, 9))
