@@ -612,7 +612,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PT_ST
     p.live = p.parked = false;
     Branches<kTree> br;
     BvhWalk walk;
-    walk.inv = splat(0.0f);
+    walk.inv = walk.oi = splat(0.0f);
+    walk.slack0 = 0.0f;
     walk.u = UnorderedBest{0.0f, -1, 0.0f, -1};
     walk.cur = kBvhDone;
     walk.sp = w.queue.stack;
@@ -767,6 +768,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PT_ST
 #endif
     count_block(a.counters, w.tally, rays, rays - shared, done, iters, tid, nthreads);
 }
+
+#include "pt_duo.h"
 
 // The closest hit of every pixel's primary ray, once per frame.  The reference
 // sends the same un-jittered ray for every sample of a pixel
@@ -1070,9 +1073,27 @@ hipError_t launch_samplekernel(const LaunchArgs &a, uint32_t block,
     return launch_sample_dispatch(b, grid, block, lds, stream);
 }
 
+// Two paths per lane (pt_duo.h): non-branching scenes, records in global memory,
+// one wave per workgroup.
+static hipError_t launch_duo(const LaunchArgs &a, uint32_t grid, hipStream_t stream) {
+    const size_t lds_bytes = duo_lds_bytes(a.max_bounces, a.scene.bvh_depth);
+    if (lds_bytes > 64u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pt_duokernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess)
+            return e;
+    }
+    hipLaunchKernelGGL(pt_duokernel, dim3(grid), dim3(64), lds_bytes, stream, a, a.scene.geom,
+                       a.scene.tri, a.scene.mat, a.scene.meta, a.scene.link,
+                       reinterpret_cast<float4 *>(a.sample_buf), a.chunk_counter);
+    return hipGetLastError();
+}
+
 template <bool kTree>
 static hipError_t launch_sample_scan(const LaunchArgs &a, uint32_t grid, uint32_t block,
                                      size_t lds, hipStream_t stream) {
+    if (!kTree && a.screened == 2u && a.stream_walks == 2u && !a.scene_in_lds && block == 64u)
+        return launch_duo(a, grid, stream);
     if (a.screened == 2u && a.stream_walks)
         return a.scene_in_lds
                    ? launch_sample_variant<true, 2, true, kTree>(a, grid, block, lds, stream)

@@ -449,6 +449,53 @@ __device__ __forceinline__ NodeBoxes load_node(const SceneRecords &rec, uint32_t
     return n;
 }
 
+// Slab test of one box for a ray given as 1/d (`inv`, approximate), -o/d
+// (`oi`) and `slack0`: false only if the ray CERTAINLY misses the box or the box
+// lies wholly beyond `best`.  t = lo * inv + oi is one fused multiply-add per
+// plane where (lo - o) * inv is two operations; what the fused form loses is
+// that lo - o is exact and lo * inv - o * inv is not: its error is up to one
+// rounding of o * inv, 2^-24 |o / d| whatever the plane, so the ray carries
+// slack0 = 2^-21 max |o / d| (eight such roundings) on top of the slack
+// proportional to the distances involved.  Written as "not certainly missed":
+// fminf / fmaxf drop a NaN operand (0 * inf on a box face, or o = 0 with
+// d = 0 on an axis) and a NaN slack can only keep the box.
+struct RaySlabs {
+    V3 inv, oi;
+    float slack0;
+};
+__device__ __forceinline__ RaySlabs ray_slabs(V3 o, V3 d) {
+    RaySlabs r;
+    r.inv = V3{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)};
+    r.oi = V3{-o.x * r.inv.x, -o.y * r.inv.y, -o.z * r.inv.z};
+    // A direction component that is +-0 (or too small for a finite reciprocal)
+    // makes -o / d infinite, and lo * inf - inf is NaN on one plane of a slab
+    // and -inf on the other where (lo - o) * inf was -inf and +inf: a box whose
+    // slab holds the origin looked left behind (found by the differential run
+    // against the linear scan: 17 of configuration 5's 447 million rays, 3
+    // pixels).  Such an axis -- and one whose o / d overflows -- is dropped
+    // instead: a NaN on both planes, which fminf / fmaxf ignore.  (An eye ray
+    // with o = 0 gets there by itself: -0 * inf is NaN.)
+    const float nan = __builtin_nanf("");
+    r.oi.x = fabsf(r.oi.x) < __builtin_inff() ? r.oi.x : nan;
+    r.oi.y = fabsf(r.oi.y) < __builtin_inff() ? r.oi.y : nan;
+    r.oi.z = fabsf(r.oi.z) < __builtin_inff() ? r.oi.z : nan;
+    r.slack0 = 0x1.0p-21f * fmaxf(fmaxf(fabsf(r.oi.x), fabsf(r.oi.y)), fabsf(r.oi.z));
+    return r;
+}
+__device__ __forceinline__ bool box_crossed(const F4 lo, const F4 hi, V3 inv, V3 oi, float slack0,
+                                            float best, float &enter) {
+    const float x0 = __builtin_fmaf(lo.x, inv.x, oi.x), x1 = __builtin_fmaf(hi.x, inv.x, oi.x);
+    const float y0 = __builtin_fmaf(lo.y, inv.y, oi.y), y1 = __builtin_fmaf(hi.y, inv.y, oi.y);
+    const float z0 = __builtin_fmaf(lo.z, inv.z, oi.z), z1 = __builtin_fmaf(hi.z, inv.z, oi.z);
+    enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    const float leave = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    const float slack = __builtin_fmaf(PT_BOX_SLACK, fabsf(enter) + fabsf(leave), slack0);
+    // (leave - enter < -slack) | (leave < -slack), as one comparison
+    const bool missed = (enter == __builtin_inff()) | (leave == -__builtin_inff()) |
+                        (leave + slack < fmaxf(enter, 0.0f)) | (enter - slack > best);
+    return !missed;
+}
+
 struct UnorderedBest {
     float best;     // smallest positive distance so far
     int best_idx;   // its object (lowest index among equals), -1: none
@@ -543,22 +590,9 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
     const bool poisoned = !(probe < __builtin_inff()) || direction_is_not_unit(d);
     walking = !poisoned;
 
-    const V3 inv = V3{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y),
-                      __builtin_amdgcn_rcpf(d.z)};
-    // slab test of one box: false only if the ray certainly misses it or the
-    // box lies wholly beyond `u.best`
+    const RaySlabs slabs = ray_slabs(o, d);
     auto crosses = [&](const F4 lo, const F4 hi, float &enter) {
-        const float x0 = (lo.x - o.x) * inv.x, x1 = (hi.x - o.x) * inv.x;
-        const float y0 = (lo.y - o.y) * inv.y, y1 = (hi.y - o.y) * inv.y;
-        const float z0 = (lo.z - o.z) * inv.z, z1 = (hi.z - o.z) * inv.z;
-        // fminf/fmaxf drop a NaN operand (0 * inf on a box face)
-        enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-        const float leave = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-        const float slack = PT_BOX_SLACK * (fabsf(enter) + fabsf(leave));
-        const bool missed = (enter == __builtin_inff()) | (leave == -__builtin_inff()) |
-                            (leave - enter < -slack) | (leave < -slack) |
-                            (enter - slack > u.best);
-        return !missed;
+        return box_crossed(lo, hi, slabs.inv, slabs.oi, slabs.slack0, u.best, enter);
     };
     constexpr uint32_t kDone = 0xFFFFFFFFu; // not a valid ref: count field would be 7
     for (int walk = 0; walk < 2; ++walk) {
@@ -666,6 +700,8 @@ constexpr uint32_t kBvhDone = 0xFFFFFFFFu; // not a valid ref: count field would
 
 struct BvhWalk {
     V3 inv;             // 1 / direction (approximate: boxes only)
+    V3 oi;              // -origin / direction ...
+    float slack0;       // ... and the slack that pays for it (box_crossed)
     UnorderedBest u;
     uint32_t cur;       // ref being visited, kBvhDone: nothing left to visit
     uint32_t *sp;       // next free entry of this lane's stack
@@ -698,8 +734,10 @@ __device__ __forceinline__ void bvh_walk_begin(const SceneRecords &rec,
 __device__ __forceinline__ void bvh_walk_first(const SceneRecords &rec,
                                                const ScreenQueue q, V3 o, V3 d,
                                                BvhWalk &w) {
-    w.inv = V3{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y),
-               __builtin_amdgcn_rcpf(d.z)};
+    const RaySlabs slabs = ray_slabs(o, d);
+    w.inv = slabs.inv;
+    w.oi = slabs.oi;
+    w.slack0 = slabs.slack0;
     w.u.best = __builtin_inff();
     w.u.best_idx = -1;
     w.u.deg_dist = 0.0f;
@@ -742,16 +780,7 @@ __device__ __forceinline__ void bvh_walk_quantum(const SceneRecords &rec,
     // have candidates (or one has 8, or nothing else can move): measured on
     // configuration 5, worth 3 % over "as soon as any lane can".
     auto crosses = [&](const F4 lo, const F4 hi, float &enter) {
-        const float x0 = (lo.x - o.x) * w.inv.x, x1 = (hi.x - o.x) * w.inv.x;
-        const float y0 = (lo.y - o.y) * w.inv.y, y1 = (hi.y - o.y) * w.inv.y;
-        const float z0 = (lo.z - o.z) * w.inv.z, z1 = (hi.z - o.z) * w.inv.z;
-        enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-        const float leave = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-        const float slack = PT_BOX_SLACK * (fabsf(enter) + fabsf(leave));
-        const bool missed = (enter == __builtin_inff()) | (leave == -__builtin_inff()) |
-                            (leave - enter < -slack) | (leave < -slack) |
-                            (enter - slack > w.u.best);
-        return !missed;
+        return box_crossed(lo, hi, w.inv, w.oi, w.slack0, w.u.best, enter);
     };
     auto pop = [&]() {
         if (w.sp != q.stack) {

@@ -1160,6 +1160,11 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
                 q.primary_hits = sc->primary;
             // resumable walks: settle_lanes = lanes waiting before a service stage
             q.stream_walks = 1u;
+            if (!*&a.tree && !a.scene_in_lds && block == 64u) { // two paths per lane (pt_duo.h)
+                const char *duo = std::getenv("PTGPU_DUO");
+                if (duo != nullptr && duo[0] == '1')
+                    q.stream_walks = 2u;
+            }
             q.settle_lanes = p->settle_lanes ? p->settle_lanes : kStreamServiceLanes;
             q.walk_budget = stream_walk_budget();
             static const uint32_t leaf_lanes = stream_knob("PTGPU_LEAF_LANES", 16u);
@@ -1168,6 +1173,21 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
             q.resolve_lanes = resolve_lanes;
             q.reshade_lanes = kStreamReshadeLanes;
             q.shade_lanes = kStreamShadeLanes;
+            if (q.stream_walks == 2u) { // (tuning knobs, read per call)
+                auto knob = [](const char *name, uint32_t fallback) {
+                    const char *e = std::getenv(name);
+                    if (e == nullptr)
+                        return fallback;
+                    const long x = std::strtol(e, nullptr, 10);
+                    return (x >= 1 && x <= 1024) ? (uint32_t)x : fallback;
+                };
+                q.settle_lanes = p->settle_lanes ? p->settle_lanes : knob("PTGPU_DUO_SERVICE", kStreamServiceLanes);
+                q.shade_lanes = knob("PTGPU_DUO_SHADE", q.shade_lanes);
+                q.reshade_lanes = knob("PTGPU_DUO_RESHADE", q.reshade_lanes);
+                q.leaf_lanes = knob("PTGPU_DUO_LEAF", q.leaf_lanes);
+                q.resolve_lanes = knob("PTGPU_DUO_RESOLVE", q.resolve_lanes);
+                q.walk_budget = knob("PTGPU_DUO_BUDGET", q.walk_budget);
+            }
         }
         hipError_t e = L.samplekernel(q, block, sc->max_waves, stream);
         if (e != hipSuccess)

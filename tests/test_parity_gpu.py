@@ -2407,6 +2407,19 @@ def test_randomised_rays_through_randomised_scenes_in_every_scan_form(gpu, oracl
             o[kinds == 2, 1] = np.inf
             d[kinds == 3] *= f32(1e30)
             o[kinds == 4] *= f32(1e20)
+            # unit directions with components that are exactly +-0 or too small to have a finite
+            # reciprocal, from origins inside the scene: a slab test must treat such an axis as
+            # "inside the slab or never" (the fused box test of round 3 first did not)
+            axis = (kinds >= 5) & (kinds <= 12)
+            for i in np.nonzero(axis)[0]:
+                v = d[i].astype(np.float64)
+                zero = rng.permutation(3)[: int(rng.integers(1, 3))]
+                v[zero] = 0.0
+                if not v.any():
+                    v[int(rng.integers(0, 3))] = 1.0
+                v /= np.linalg.norm(v)
+                d[i] = v.astype(f32)
+                d[i, zero] = rng.choice([0.0, -0.0, 1e-42, -1e-40, 3e-39]).astype(f32) if kinds[i] % 2 else f32(0)
             want = oracle.trace_rays(s, o, d)
             hit = want[0] >= 0
             scans = [A.FLAG_SCAN_PLAIN, A.FLAG_SCAN_SCREENED] + ([A.FLAG_SCAN_BVH] if s.num_objects >= 64 else [])
