@@ -78,6 +78,16 @@ def flop_per_ray(n_spheres, n_triangles):
     return 17 * n_spheres + 45 * n_triangles + 100
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(pt, scene, cfg, gpu_frame_rows):
     """The oracle on this machine's host cores, on a bounded sample of the same
     frame: every 8th row with the GPU's stream on all cores (corrected row
@@ -88,6 +98,8 @@ def cpu_baseline(pt, scene, cfg, gpu_frame_rows):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    affinity = cores
+    nproc = os.cpu_count() or cores
     cores = max(1, min(cores, 16))   # a one-GPU box's CPU share is 16 cores
     w, h = cfg["width"], cfg["height"]
     kw = dict(spp=cfg["spp"], max_bounces=cfg["max_bounces"], seed=cfg["seed"])
@@ -99,6 +111,7 @@ def cpu_baseline(pt, scene, cfg, gpu_frame_rows):
     rows = list(range(0, h, step))
     out = {
         "value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+        "host": {"nproc": nproc, "affinity": affinity, "threads_used": cores, "cpu": cpu_model()},
         "sample": f"rows 0,{step},{2*step},... ({len(rows)} of {h}) of the same frame, "
                   f"{rays} rays in {dt:.2f} s; CPU oracle (restated reference, "
                   "per-pixel xorshift stream) on a corrected row-task pool",
@@ -226,6 +239,7 @@ def main():
         frame = None
 
     kernel_ms = []
+    gather_ms = []
     # parameter blocks are built once, outside the timed loop
     frame_params = pt.make_params(spp=cfg["spp"], **base)
     pass_params = [pt.make_params(spp=pass_spp, sample_offset=k * pass_spp,
@@ -254,6 +268,12 @@ def main():
                 got = got.cuda() if got is not None else None
             if rank == 0:
                 frame = got
+            # (the collective has been waited for on this stream: the event
+            # closes the gather + un-interleave as this rank saw them)
+            ev2 = torch.cuda.Event(enable_timing=True)
+            ev2.record()
+            if timed:
+                gather_ms.append((ev1, ev2))
         if timed:
             kernel_ms.append((ev0, ev1))
 
@@ -291,6 +311,13 @@ def main():
     rays, samples, wave_iters = (float(x) for x in counts.tolist())
     elapsed = float(tmax.item())
     kernel_ms_avg = float(kmax.item())
+    # what each rank did, so that a sub-linear point of a scaling curve can be
+    # attributed: kernel time per rank, the gather as each rank saw it, imbalance
+    per_rank = None
+    if world > 1:
+        my_kernel = sum(a.elapsed_time(b) for a, b in kernel_ms) / max(1, len(kernel_ms))
+        my_gather = sum(a.elapsed_time(b) for a, b in gather_ms) / max(1, len(gather_ms))
+        per_rank = tiles.scaling_report(my_kernel, my_gather, h, w, tile)
 
     if rank == 0:
         rays_per_step = rays / args.steps
@@ -372,6 +399,12 @@ def main():
             rf["achieved"], rf["frac"], rf["flop_per_ray"] = work["achieved"], work["frac"], work["flop_per_ray"]
             rf["note"] += "; flop_per_ray = " + work["note"]
         assert st.scans == st.rays, "headline must scan the scene for every counted ray"
+        if per_rank is not None:
+            per_rank["backend"] = "RCCL (torch nccl)" if args.backend == "nccl" else "gloo rehearsal (ranks share devices)"
+            per_rank["note"] = ("kernel_ms / gather_ms: per rank, per frame, HIP events on the rank's stream; "
+                                "imbalance = max / mean of kernel_ms; ms_per_step is the wall clock between "
+                                "the barriers, maximum over ranks")
+            line["ranks"] = per_rank
         if world == 1 and not progressive:
             # library default: primary-ray scan shared between a pixel's samples
             shared = pt.make_params(spp=cfg["spp"], **{**base, "flags": base["flags"] & ~pt._abi.FLAG_NO_PRIMARY_SHARE})

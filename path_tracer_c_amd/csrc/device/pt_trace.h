@@ -490,9 +490,11 @@ __device__ __forceinline__ bool box_crossed(const F4 lo, const F4 hi, V3 inv, V3
     enter = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
     const float leave = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
     const float slack = __builtin_fmaf(PT_BOX_SLACK, fabsf(enter) + fabsf(leave), slack0);
-    // (leave - enter < -slack) | (leave < -slack), as one comparison
-    const bool missed = (enter == __builtin_inff()) | (leave == -__builtin_inff()) |
-                        (leave + slack < fmaxf(enter, 0.0f)) | (enter - slack > best);
+    // (leave - enter < -slack) | (leave < -slack), as one comparison.  An
+    // infinite `enter` or `leave` (a product that overflows: box coordinates are
+    // finite or point away from the box, and an infinite 1 / d was dropped above)
+    // makes the slack infinite and every comparison false: the box is kept.
+    const bool missed = (leave + slack < fmaxf(enter, 0.0f)) | (enter - slack > best);
     return !missed;
 }
 

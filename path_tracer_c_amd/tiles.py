@@ -108,3 +108,38 @@ def gather_frame(local_rows, height: int, width: int, tile_rows: int,
     # one scatter un-interleaves all ranks' tiles (padding rows land in the spare row)
     scratch["frame"].index_copy_(0, scratch["index"], stack.view(world * pad, width, 3))
     return scratch["frame"][:height]
+
+
+def gather_bytes(height: int, width: int, world: int, tile_rows: int) -> dict:
+    """What the one gather of a frame moves: every rank sends its padded compact
+    buffer (equal message sizes), rank 0 receives world - 1 of them over xGMI."""
+    pad = max_shard_rows(height, world, tile_rows)
+    message = pad * width * 3
+    return {"message_bytes_per_rank": message, "received_by_root": message * (world - 1),
+            "frame_bytes": height * width * 3}
+
+
+def scaling_report(kernel_ms: float, gather_ms: float, height: int, width: int,
+                   tile_rows: int, group=None) -> dict:
+    """Per-rank figures that make a scaling curve explainable (all ranks call
+    this; every rank gets the same dict): each rank's kernel time per frame
+    (HIP events around its render launches), the time of the gather as each
+    rank saw it, the imbalance max / mean of the kernel times, the bytes the
+    gather moved, and how many ranks the process group really has."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    mine = (float(kernel_ms), float(gather_ms))
+    if world > 1:
+        both = [None] * world
+        dist.all_gather_object(both, mine, group=group)
+    else:
+        both = [mine]
+    kernel = [b[0] for b in both]
+    gather = [b[1] for b in both]
+    mean = sum(kernel) / len(kernel)
+    return {"ranks_seen": world,
+            "kernel_ms": kernel,
+            "gather_ms": gather,
+            "imbalance": (max(kernel) / mean) if mean > 0 else None,
+            "gather": gather_bytes(height, width, world, tile_rows)}

@@ -1861,6 +1861,35 @@ def test_bench_lines_of_the_other_configs_parse(gpu, workload, scene, w, h, spp)
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
 
 
+def test_bench_line_of_two_ranks_carries_per_rank_figures(gpu):
+    """`bench.py --gpus 2` in its rehearsal form (gloo, both ranks on this GPU):
+    the line keeps the contract's keys and adds `ranks` -- per-rank kernel ms,
+    gather ms, imbalance, the bytes of the one gather, the ranks the process
+    group really has -- and the gathered frame equals the single-launch frame."""
+    import json
+    import socket
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "c4",
+                          "--spp", "8", "--steps", "2", "--warmup", "1", "--verify"],
+                         check=True, capture_output=True, text=True, timeout=600, cwd=str(root)).stdout
+    line = json.loads([ln for ln in out.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["verified_equal_to_single_launch"] is True
+    assert "config 4" in line["config"]["workload"] and "3840x2160" in line["config"]["workload"]
+    ranks = line["ranks"]
+    assert ranks["ranks_seen"] == 2
+    assert len(ranks["kernel_ms"]) == 2 and len(ranks["gather_ms"]) == 2
+    assert all(ms > 0 for ms in ranks["kernel_ms"]) and all(ms >= 0 for ms in ranks["gather_ms"])
+    assert 1.0 <= ranks["imbalance"] < 2.0
+    assert ranks["gather"] == {"message_bytes_per_rank": 1080 * 3840 * 3, "received_by_root": 1080 * 3840 * 3,
+                               "frame_bytes": 2160 * 3840 * 3}
+
+
 # ---- the opt-in tolerance mode (PTGPU_FLAG_FAST_MATH, round 2) -----------------------------
 def _fast_vs_exact(gpu, torch_cuda, scene, w, h, **kw):
     A = gpu._abi

@@ -87,3 +87,55 @@ def test_two_rank_gloo_gather_reassembles_the_frame(tmp_path, pt, oracle, height
     with pt.HostScene(1) as scene:
         ref, _ = oracle.render_rows(scene, width, height, spp=4, seed=11)
     assert np.array_equal(got, ref)
+
+
+def _report_main(rank, world, port, out_path):
+    import json
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank r pretends its kernel took 10 + 2r ms and the gather 0.5 + r ms
+        rep = tiles.scaling_report(10.0 + 2.0 * rank, 0.5 + rank, 2160, 3840, 8)
+        with open(f"{out_path}.{rank}", "w") as f:
+            json.dump(rep, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_scaling_report_carries_every_ranks_figures(tmp_path):
+    """What `bench.py --gpus N` adds to its line (`ranks`): per-rank kernel and
+    gather times, the imbalance and the bytes of the one gather -- here over two
+    gloo ranks with made-up timings; every rank ends up with the same report."""
+    import json
+
+    import torch.multiprocessing as mp
+
+    world = 2
+    out = tmp_path / "report"
+    mp.spawn(_report_main, args=(world, _free_port(), str(out)), nprocs=world, join=True)
+    reps = [json.load(open(f"{out}.{r}")) for r in range(world)]
+    assert reps[0] == reps[1]
+    rep = reps[0]
+    assert rep["ranks_seen"] == 2
+    assert rep["kernel_ms"] == [10.0, 12.0] and rep["gather_ms"] == [0.5, 1.5]
+    assert rep["imbalance"] == pytest.approx(12.0 / 11.0)
+    # configuration 4 over two ranks: 1080 rows of 3840 RGB pixels each
+    assert rep["gather"] == {"message_bytes_per_rank": 1080 * 3840 * 3,
+                             "received_by_root": 1080 * 3840 * 3, "frame_bytes": 2160 * 3840 * 3}
+
+
+def test_scaling_report_without_a_process_group_is_the_one_rank_case():
+    rep = tiles.scaling_report(62.5, 0.0, 1080, 1920, 8)
+    assert rep["ranks_seen"] == 1 and rep["kernel_ms"] == [62.5] and rep["imbalance"] == 1.0
+    assert rep["gather"]["received_by_root"] == 0
+
+
+def test_gather_bytes_match_the_survey_message_sizes():
+    """at configuration 4 each rank sends 12.4 / 6.2 / 3.1 MB at G = 2 / 4 / 8."""
+    for world, mb in ((2, 12.4), (4, 6.2), (8, 3.1)):
+        b = tiles.gather_bytes(2160, 3840, world, 8)
+        assert b["message_bytes_per_rank"] / 1e6 == pytest.approx(mb, abs=0.1)   # (padded to the largest shard)
