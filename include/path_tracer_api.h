@@ -187,6 +187,10 @@ typedef struct {
 void threadpool_init(threadpool *pool, size_t num_threads);
 /* Running tasks finish; queued ones are dropped (src/threadpool.c:60-82). */
 void threadpool_destroy(threadpool *pool);
+/* A render_task row is COPIED from *arg here, when it is queued (the reference
+ * copies it when a worker starts the task, src/renderer.c:93: a caller that
+ * patches or reuses the struct between queuing and waiting gets the values of
+ * queuing time here, a race there).  Any other task gets `arg` itself. */
 void threadpool_add_task(threadpool *pool, void (*f)(void *), void *arg);
 /* Returns only when every task added so far has completed. */
 void threadpool_wait_for_tasks(threadpool *pool);

@@ -254,11 +254,20 @@ int ptgpu_scene_hierarchy(const ptgpu_scene *s, uint32_t *nodes, uint32_t *depth
 int ptgpu_scene_tune(const ptgpu_scene *s, size_t framew, size_t frameh, const ptgpu_params *p);
 
 /* -- rendering ------------------------------------------------------------- */
-/* Asynchronous (never synchronises the stream; see ptgpu_scene_tune): renders the row set of `p` of a framew x frameh image into
+/* Asynchronous: renders the row set of `p` of a framew x frameh image into
  * `d_frame` (device memory, RGB8, 3*framew bytes per row) on `hip_stream`
- * (a hipStream_t, NULL = default stream).  Bytes written equal, bit for bit,
- * what the reference's render_task would store for the same stream of random
- * numbers (src/renderer.c:92-116). */
+ * (a hipStream_t, NULL = default stream) and returns without waiting.  It
+ * never measures (see ptgpu_scene_tune).  It does not synchronise either,
+ * with one exception: a sample-queue pass that finds the per-device scratch
+ * too small -- first use, a larger frame than any before, after
+ * ptgpu_release_scratch -- grows it, and hipFree / hipMalloc wait for the
+ * device.  ptgpu_scene_tune with the same frame size and parameters leaves the
+ * scratch sized for them, so a tuned scene's calls do not allocate.
+ * Bytes written equal, bit for bit, what the reference's render_task would
+ * store for the same stream of random numbers (src/renderer.c:92-116) -- with
+ * the one stated limit of the two scan forms that cull objects by geometry
+ * (PTGPU_FLAG_SCAN_SCREENED / _BVH, the default from 32 objects on) on scenes
+ * with TRIANGLES: see "in-plane rays" under PTGPU_FLAG_SCAN_PLAIN above. */
 int ptgpu_render_device(const ptgpu_scene *s, uint8_t *d_frame, size_t framew,
                         size_t frameh, const ptgpu_params *p,
                         void *hip_stream);
@@ -372,6 +381,29 @@ int ptgpu_stats_read(ptgpu_stats *out); /* synchronises the device */
 int ptgpu_release_scratch(void);
 const char *ptgpu_last_error(void);     /* thread-local, never NULL */
 const char *ptgpu_version(void);
+
+/* -- the legacy entry points' two policies (environment, read per call) ------
+ * render_task / threadpool_* / trace_ray return void in the reference
+ * (include/renderer.h:13, include/threadpool.h:15-20) and cannot report a
+ * failure.
+ *   PTGPU_ON_ERROR=abort (default)  a failed legacy call prints the reason and
+ *                    abort()s: there is no CPU renderer to fall back to, and a
+ *                    frame that silently stays black is worse than none.
+ *   PTGPU_ON_ERROR=zero   the call writes nothing (trace_ray returns the
+ *                    reference's "no hit", distance -1), prints the reason on
+ *                    stderr once per process and returns; ptgpu_last_error()
+ *                    has it.  For a host program that must outlive a
+ *                    transient HIP failure.
+ *   PTGPU_FRAME_SEED=auto  every legacy frame draws from the stream PTGPU_SEED
+ *                    + (frames rendered before it), the analogue of the fresh
+ *                    random_seed the reference's real-time loop takes per frame
+ *                    (src/main.c:276).  A frame is one threadpool_wait_for_tasks
+ *                    that rendered rows or, for render_task called directly, the
+ *                    calls up to the first row asked for a second time.
+ *                    Default: PTGPU_SEED for every frame (the same picture for
+ *                    the same scene).
+ * Number of legacy frames counted so far under PTGPU_FRAME_SEED=auto: */
+uint32_t ptgpu_legacy_frames(void);
 
 /* -- synthetic scenes of BASELINE.json's five configurations --------------- */
 /* Fills an initialised-or-not `scene` (scene_init is called inside) with

@@ -243,6 +243,7 @@ SIGNATURES = {
     "ptgpu_stats_read": (C.c_int, [C.POINTER(Stats)]),
     "ptgpu_last_error": (C.c_char_p, []),
     "ptgpu_version": (C.c_char_p, []),
+    "ptgpu_legacy_frames": (C.c_uint32, []),
     "ptgpu_build_config_scene": (C.c_int, [C.c_int, C.POINTER(Scene)]),
 }
 

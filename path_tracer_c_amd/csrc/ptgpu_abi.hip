@@ -1901,10 +1901,22 @@ int ptgpu_multi_render(ptgpu_multi *m, uint8_t *d_frame, size_t framew, size_t f
 
     int home = 0;
     PT_TRY_HIP(hipGetDevice(&home));
-    struct Restore {
+    // Whichever way this function is left -- the early returns of a failed HIP
+    // call below included -- every stream is drained first: kernels already
+    // enqueued on other shards' streams write m->shards and m->stage, and the
+    // contract is that the call returns when the frame is complete (or failed)
+    // and the buffers are free for the next call.
+    struct DrainAndRestore {
+        ptgpu_multi *m;
         int home;
-        ~Restore() { (void)hipSetDevice(home); }
-    } restore{home};
+        ~DrainAndRestore() {
+            for (size_t r = 0; r < m->devices.size(); ++r) {
+                (void)hipSetDevice(m->devices[r]);
+                (void)hipStreamSynchronize(m->streams[r]);
+            }
+            (void)hipSetDevice(home);
+        }
+    } drain_and_restore{m, home};
 
     PT_TRY_HIP(hipSetDevice(m->devices[0]));
     int rc = ensure(&m->stage, total ? total : 16);
@@ -2237,6 +2249,40 @@ namespace {
     std::abort();
 }
 
+// What a legacy call does when the device path fails.  The reference's
+// functions return void and cannot report anything (src/renderer.c:92,
+// src/threadpool.c:84-101), so the default is to stop loudly: a picture that
+// silently stays black is worse than no picture.  PTGPU_ON_ERROR=zero (read
+// per call) is the opt-out for a host program that must survive a transient
+// HIP failure: the call writes nothing, says why on stderr -- once per
+// process -- and returns; ptgpu_last_error() holds the reason.
+bool legacy_failed(const char *who) {
+    const char *policy = std::getenv("PTGPU_ON_ERROR");
+    if (policy == nullptr || std::strcmp(policy, "zero") != 0)
+        die(who);
+    static std::atomic<bool> said{false};
+    if (!said.exchange(true))
+        std::fprintf(stderr,
+                     "path_tracer (MI355X path): %s failed: %s\n"
+                     "  PTGPU_ON_ERROR=zero: the call wrote nothing; later failures are not reported here "
+                     "(ptgpu_last_error()).\n",
+                     who, g_last_error.c_str());
+    return false;
+}
+
+// PTGPU_FRAME_SEED=auto: every frame rendered through the legacy calls gets the
+// stream `PTGPU_SEED + number of frames before it`, the analogue of the
+// reference's real-time loop, which draws a fresh random_seed per frame
+// (src/main.c:276).  Without it a legacy frame of an unchanged scene is the
+// same picture every time (PTGPU_SEED is all the legacy API can say).  A frame
+// is one threadpool_wait_for_tasks that rendered rows, or, for render_task
+// called directly, the calls up to the first row asked for a second time.
+std::atomic<uint32_t> g_legacy_frames{0};
+bool frame_seed_auto() {
+    const char *e = std::getenv("PTGPU_FRAME_SEED");
+    return e != nullptr && std::strcmp(e, "auto") == 0;
+}
+
 // One cached device scene for the legacy calls, revalidated by content hash
 // so a caller may edit its scene between frames (the reference's RT loop
 // does, src/main.c:260-263).
@@ -2249,41 +2295,64 @@ struct CachedScene {
 std::mutex g_cache_mutex;
 CachedScene g_cache;
 
-uint64_t fnv1a(const void *data, size_t n, uint64_t h) {
+// Content hash of a byte range: four independent multiply-xorshift lanes over
+// 8-byte words (a direct render_task call checks the whole scene per row, and a
+// byte-at-a-time FNV of a 200 000-triangle scene was 10 ms per row).  Detects
+// edits; not cryptographic.
+uint64_t hash_bytes(const void *data, size_t n, uint64_t seed) {
     const unsigned char *p = static_cast<const unsigned char *>(data);
-    for (size_t i = 0; i < n; ++i) {
-        h ^= p[i];
-        h *= 0x100000001B3ull;
+    constexpr uint64_t kMul = 0x9E3779B97F4A7C15ull;
+    uint64_t h[4] = {seed ^ 0xCBF29CE484222325ull, seed + 0x100000001B3ull, ~seed, seed * kMul + 1u};
+    while (n >= 32) {
+        uint64_t w[4];
+        std::memcpy(w, p, 32);
+        for (int k = 0; k < 4; ++k) {
+            h[k] = (h[k] ^ w[k]) * kMul;
+            h[k] ^= h[k] >> 29;
+        }
+        p += 32;
+        n -= 32;
     }
-    return h;
+    uint64_t tail = (uint64_t)n;
+    for (size_t i = 0; i < n; ++i)
+        tail = (tail ^ p[i]) * 0x100000001B3ull;
+    uint64_t out = tail;
+    for (int k = 0; k < 4; ++k) {
+        out = (out ^ h[k]) * kMul;
+        out ^= out >> 32;
+    }
+    return out;
 }
 
 uint64_t scene_hash(const scene *w) {
-    uint64_t h = 0xCBF29CE484222325ull;
-    h = fnv1a(&w->num_objects, sizeof w->num_objects, h);
-    h = fnv1a(&w->num_materials, sizeof w->num_materials, h);
-    h = fnv1a(&w->sky_color, sizeof w->sky_color, h);
+    uint64_t h = hash_bytes(&w->num_objects, sizeof w->num_objects, 1);
+    h = hash_bytes(&w->num_materials, sizeof w->num_materials, h);
+    h = hash_bytes(&w->sky_color, sizeof w->sky_color, h);
     if (w->num_objects)
-        h = fnv1a(w->objects, w->num_objects * sizeof(shape), h);
+        h = hash_bytes(w->objects, w->num_objects * sizeof(shape), h);
     if (w->num_materials)
-        h = fnv1a(w->materials, w->num_materials * sizeof(shape_material), h);
+        h = hash_bytes(w->materials, w->num_materials * sizeof(shape_material), h);
     return h;
 }
 
-// Returns the cached device copy of `w`, uploading if it changed.
-ptgpu_scene *legacy_scene(const scene *w) {
+// Returns the cached device copy of `w` (content hash `h`), uploading if it
+// changed; nullptr if that failed and the error policy lets the call return.
+ptgpu_scene *legacy_scene(const scene *w, uint64_t h) {
     int dev = 0;
-    if (current_device(&dev) != PTGPU_OK)
-        die("hipGetDevice");
-    const uint64_t h = scene_hash(w);
+    if (current_device(&dev) != PTGPU_OK) {
+        legacy_failed("hipGetDevice");
+        return nullptr;
+    }
     if (g_cache.dev != nullptr && g_cache.key == w && g_cache.hash == h &&
         g_cache.device == dev)
         return g_cache.dev;
     ptgpu_scene_free(g_cache.dev);
     g_cache = CachedScene();
     ptgpu_scene *s = nullptr;
-    if (ptgpu_scene_upload(w, &s) != PTGPU_OK)
-        die("scene upload");
+    if (ptgpu_scene_upload(w, &s) != PTGPU_OK) {
+        legacy_failed("scene upload");
+        return nullptr;
+    }
     g_cache.key = w;
     g_cache.hash = h;
     g_cache.device = dev;
@@ -2291,12 +2360,13 @@ ptgpu_scene *legacy_scene(const scene *w) {
     return s;
 }
 
-void legacy_render_rows(const scene *world, uint8_t *frame, size_t framew,
+// Rows [row_begin, row_begin + num_rows) of the frame with the settings `p`
+// (row fields are set here).  `hash`: the scene's content hash if the caller
+// has it already.  False: failed, nothing written (PTGPU_ON_ERROR=zero).
+bool legacy_render_rows(const scene *world, uint8_t *frame, size_t framew,
                         size_t frameh, uint32_t row_begin, uint32_t num_rows,
-                        bool dest_compact = false) {
+                        ptgpu_params p, bool dest_compact = false, const uint64_t *hash = nullptr) {
     std::lock_guard<std::mutex> guard(g_cache_mutex);
-    ptgpu_params p;
-    ptgpu_params_from_env(&p);
     p.row_begin = row_begin;
     p.num_rows = num_rows;
     p.tile_rows = 0;
@@ -2305,7 +2375,7 @@ void legacy_render_rows(const scene *world, uint8_t *frame, size_t framew,
     if (!dest_compact && env_u32("PTGPU_DEVICES", &n_dev) && n_dev > 1 && num_rows >= 2 * n_dev) {
         int have = ptgpu_device_count();
         if (have < 1)
-            die("device count");
+            return legacy_failed("device count");
         if ((int)n_dev > kMaxDevices)
             n_dev = kMaxDevices;
         std::vector<int> devices(n_dev);
@@ -2313,14 +2383,16 @@ void legacy_render_rows(const scene *world, uint8_t *frame, size_t framew,
             devices[i] = (int)(i % (uint32_t)have);
         if (ptgpu_render_frame_multi(world, frame, framew, frameh, &p, devices.data(),
                                      (int)n_dev, 0) != PTGPU_OK)
-            die("multi-device render");
-        return;
+            return legacy_failed("multi-device render");
+        return true;
     }
-    ptgpu_scene *s = legacy_scene(world);
+    ptgpu_scene *s = legacy_scene(world, hash != nullptr ? *hash : scene_hash(world));
+    if (s == nullptr)
+        return false;
     if (render_frame_with(s, frame, framew, frameh, &p, dest_compact) != PTGPU_OK)
-        die("render");
+        return legacy_failed("render");
+    return true;
 }
-
 
 } // namespace
 
@@ -2333,11 +2405,14 @@ void legacy_render_rows(const scene *world, uint8_t *frame, size_t framew,
 // can be done AHEAD: when calls walk the rows in order, the next miss renders
 // twice as many rows as the last one (1, 2, 4, ... up to the rest of the
 // frame; downwards or upwards) into a host-side cache, and the calls that
-// follow are a memcpy.  A
-// row is a pure function of (scene content, settings, frame size, row), which
-// is the cache's key -- a caller that edits its scene between calls gets fresh
-// rows.  A 1080-row frame costs 11 launches instead of 1080; once a frame has
-// been walked to its end the next one is fetched whole.  PTGPU_LEGACY_READAHEAD=0
+// follow are a content check and a memcpy.  A row is a pure function of (scene
+// content, settings, frame size, row), which is the cache's key -- a caller
+// that edits its scene between calls gets fresh rows (the scene is hashed once
+// per call, word-wise).  A 1080-row frame costs 11 launches instead of 1080;
+// once a frame of a VIEW -- scene pointer, frame size, settings; not the
+// content, not the frame's seed -- has been walked to its end the next one is
+// fetched whole, so a caller that animates its scene or runs with
+// PTGPU_FRAME_SEED=auto gets one launch per frame.  PTGPU_LEGACY_READAHEAD=0
 // turns it off (one row per call, as before).
 // ---------------------------------------------------------------------------
 namespace {
@@ -2346,19 +2421,23 @@ struct RowCache {
     const scene *world = nullptr;
     uint64_t hash = 0;
     size_t framew = 0, frameh = 0;
-    ptgpu_params params;          // settings the rows were rendered with
+    ptgpu_params params;          // settings the rows were rendered with (seed: the frame's)
     uint32_t row_begin = 0, num_rows = 0;
     std::vector<uint8_t> rows;    // num_rows * 3 * framew bytes
     uint32_t batch = 1;           // rows fetched by the last miss
-    bool walked_to_the_end = false; // the last frame of this key was walked sequentially
+    bool walked_to_the_end = false; // the last frame of this view was walked sequentially
     bool valid = false;
+    // PTGPU_FRAME_SEED=auto: the frame being walked and the rows it has handed out
+    bool frame_open = false;
+    uint32_t frame_index = 0;
+    std::vector<uint8_t> served;
 };
 RowCache g_row_cache;
 std::mutex g_row_cache_mutex; // held for a whole direct call; taken BEFORE g_cache_mutex
                               // (which legacy_render_rows takes inside)
 
-bool same_settings(const ptgpu_params &a, const ptgpu_params &b) {
-    return a.spp == b.spp && a.max_bounces == b.max_bounces && a.seed == b.seed &&
+bool same_settings_but_seed(const ptgpu_params &a, const ptgpu_params &b) {
+    return a.spp == b.spp && a.max_bounces == b.max_bounces &&
            __builtin_bit_cast(uint32_t, a.fov_rad) == __builtin_bit_cast(uint32_t, b.fov_rad) &&
            a.sample_offset == b.sample_offset &&
            (a.flags & (PTGPU_FLAG_FAST_MATH | PTGPU_FLAG_GLSL_SEMANTICS)) ==
@@ -2375,25 +2454,44 @@ bool readahead_enabled() {
 }
 
 void legacy_one_row(const scene *world, uint8_t *frame, size_t framew, size_t frameh, uint32_t y) {
-    if (!readahead_enabled()) {
-        legacy_render_rows(world, frame, framew, frameh, y, 1u);
-        return;
-    }
     const size_t row_bytes = 3u * framew;
     ptgpu_params now;
     ptgpu_params_from_env(&now);
-    const uint64_t h = scene_hash(world);
     RowCache &c = g_row_cache;
     std::lock_guard<std::mutex> guard(g_row_cache_mutex);
-    const bool same_key = c.valid && c.world == world && c.hash == h && c.framew == framew &&
-                          c.frameh == frameh && same_settings(c.params, now);
+    const bool same_view = c.world == world && c.framew == framew && c.frameh == frameh &&
+                           same_settings_but_seed(c.params, now);
+    if (frame_seed_auto()) {
+        // a new frame begins with a new view, or with the first row that is
+        // asked for a second time
+        if (!same_view || !c.frame_open || c.served.size() != frameh || c.served[y]) {
+            c.frame_index = g_legacy_frames.fetch_add(1);
+            c.served.assign(frameh, 0);
+            c.frame_open = true;
+        }
+        c.served[y] = 1;
+        now.seed += c.frame_index;
+    } else {
+        c.frame_open = false;
+    }
+    if (!readahead_enabled()) {
+        c.world = world;
+        c.framew = framew;
+        c.frameh = frameh;
+        c.params = now;
+        c.valid = false;
+        legacy_render_rows(world, frame, framew, frameh, y, 1u, now);
+        return;
+    }
+    const uint64_t h = scene_hash(world);
+    const bool same_key = c.valid && same_view && c.hash == h && c.params.seed == now.seed;
     if (same_key && y >= c.row_begin && y < c.row_begin + c.num_rows) {
         std::memcpy(frame + row_bytes * y, c.rows.data() + row_bytes * (y - c.row_begin), row_bytes);
         return;
     }
     // a miss: how far ahead?  Twice the last batch when this row continues the
     // walk (just past the cached rows); the whole frame when the last frame of
-    // this key was walked to its end and this one starts at the top
+    // this view was walked to its end and this one starts at the top
     // (the walk may also go UP the frame: the reference's own pool hands out
     // the newest task first, src/threadpool.c:28, i.e. the bottom row first)
     uint32_t ahead = 1;
@@ -2404,7 +2502,7 @@ void legacy_one_row(const scene *world, uint8_t *frame, size_t framew, size_t fr
     } else if (same_key && y + 1u == c.row_begin) { // continues upwards
         ahead = twice < y + 1u ? twice : y + 1u;
         begin = y + 1u - ahead;
-    } else if (same_key && c.walked_to_the_end && (y == 0 || y + 1u == frameh)) {
+    } else if (same_view && c.walked_to_the_end && (y == 0 || y + 1u == frameh)) {
         ahead = (uint32_t)frameh; // the last frame was walked through: fetch this one whole
         begin = 0;
     }
@@ -2421,7 +2519,9 @@ void legacy_one_row(const scene *world, uint8_t *frame, size_t framew, size_t fr
     c.batch = ahead;
     c.walked_to_the_end = false;
     c.rows.resize(row_bytes * ahead);
-    legacy_render_rows(world, c.rows.data(), framew, frameh, begin, ahead, /*dest_compact=*/true);
+    if (!legacy_render_rows(world, c.rows.data(), framew, frameh, begin, ahead, now,
+                            /*dest_compact=*/true, &h))
+        return; // (PTGPU_ON_ERROR=zero: nothing written, nothing cached)
     c.valid = true;
     std::memcpy(frame + row_bytes * y, c.rows.data() + row_bytes * (y - begin), row_bytes);
     if (begin == 0 || begin + ahead == frameh)
@@ -2429,6 +2529,8 @@ void legacy_one_row(const scene *world, uint8_t *frame, size_t framew, size_t fr
 }
 
 } // namespace
+
+uint32_t ptgpu_legacy_frames(void) { return g_legacy_frames.load(); }
 
 void render_task(render_args *arg) {
     if (arg == nullptr || arg->frame == nullptr || arg->world == nullptr)
@@ -2442,8 +2544,11 @@ ray_hit trace_ray(const vec3s origin, const vec3s direction,
                   const scene *world) {
     ray_hit hit;
     std::memset(&hit, 0, sizeof hit);
-    if (ptgpu_trace_rays(world, origin.raw, direction.raw, 1, &hit) != PTGPU_OK)
-        die("trace_ray");
+    if (ptgpu_trace_rays(world, origin.raw, direction.raw, 1, &hit) != PTGPU_OK) {
+        legacy_failed("trace_ray");
+        std::memset(&hit, 0, sizeof hit);
+        hit.distance = -1.0f; // (PTGPU_ON_ERROR=zero: the reference's "no hit", src/ray.c:6)
+    }
     return hit;
 }
 
@@ -2467,6 +2572,12 @@ void ptgpu_pool_render_rows(const render_args *queued, size_t n) {
         if (a->frameh != b->frameh) return a->frameh < b->frameh;
         return a->screen_y < b->screen_y;
     });
+    if (rows.empty())
+        return;
+    ptgpu_params settings;
+    ptgpu_params_from_env(&settings);
+    if (frame_seed_auto()) // one wait = one frame (every frame buffer of this wait)
+        settings.seed += g_legacy_frames.fetch_add(1);
     size_t i = 0;
     while (i < rows.size()) {
         const render_args &head = *rows[i];
@@ -2478,7 +2589,7 @@ void ptgpu_pool_render_rows(const render_args *queued, size_t n) {
             ++j;
         const int y0 = head.screen_y, y1 = rows[j - 1]->screen_y;
         legacy_render_rows(head.world, head.frame, head.framew, head.frameh, (uint32_t)y0,
-                           (uint32_t)(y1 - y0 + 1));
+                           (uint32_t)(y1 - y0 + 1), settings);
         i = j;
     }
 }

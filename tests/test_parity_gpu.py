@@ -1448,6 +1448,95 @@ def test_threadpool_render_task_frame(gpu, oracle, monkeypatch):
     assert not part[rest].any()
 
 
+def test_legacy_frame_seed_auto_gives_every_frame_its_own_stream(gpu, monkeypatch):
+    """PTGPU_FRAME_SEED=auto, the analogue of the reference's per-frame
+    random_seed (src/main.c:276): legacy frame number k of the process draws
+    from the stream PTGPU_SEED + k -- through the pool (one wait = one frame)
+    and through render_task called directly (a frame ends with the first row
+    asked for again).  Without it every frame is the PTGPU_SEED frame."""
+    A = gpu._abi
+    lib = gpu.lib()
+    monkeypatch.setenv("PTGPU_SPP", "4")
+    monkeypatch.setenv("PTGPU_BOUNCES", "3")
+    monkeypatch.setenv("PTGPU_SEED", "100")
+    w, h = 64, 40
+    with gpu.HostScene(0) as s:
+        def explicit(seed):
+            return gpu.render_frame(s, w, h, spp=4, max_bounces=3, seed=seed)
+
+        plain = [gpu.host.render_frame_legacy(s, w, h) for _ in range(2)]
+        assert np.array_equal(plain[0], plain[1]) and np.array_equal(plain[0], explicit(100))
+
+        monkeypatch.setenv("PTGPU_FRAME_SEED", "auto")
+        k0 = lib.ptgpu_legacy_frames()
+        frames = [gpu.host.render_frame_legacy(s, w, h) for _ in range(3)]
+        assert lib.ptgpu_legacy_frames() == k0 + 3
+        for k, f in enumerate(frames):
+            assert np.array_equal(f, explicit(100 + k0 + k)), k
+        assert not np.array_equal(frames[0], frames[1])
+
+        # render_task called directly, rows top to bottom, two frames and a half
+        k1 = lib.ptgpu_legacy_frames()
+        direct = np.zeros((3, h, w, 3), dtype=np.uint8)
+        for n in range(3):
+            for y in range(h if n < 2 else h // 2):
+                args = A.RenderArgs(y, w, h, direct[n].ctypes.data_as(C.POINTER(C.c_uint8)), C.pointer(s.c))
+                lib.render_task(C.byref(args))
+        assert lib.ptgpu_legacy_frames() == k1 + 3
+        for n in range(3):
+            want = explicit(100 + k1 + n)
+            rows = h if n < 2 else h // 2
+            assert np.array_equal(direct[n][:rows], want[:rows]), n
+        assert not direct[2][h // 2:].any()
+
+        monkeypatch.delenv("PTGPU_FRAME_SEED")
+        assert np.array_equal(gpu.host.render_frame_legacy(s, w, h), plain[0])
+
+
+_ON_ERROR_CHILD = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd())
+import path_tracer_c_amd as pt
+A = pt._abi
+lib = pt.lib()
+with pt.HostScene(1) as s:
+    good = pt.host.render_frame_legacy(s, 48, 32)
+    os.environ["PTGPU_BOUNCES"] = "100000"           # beyond the kernels' limit: every render call fails
+    frame = np.full((32, 48, 3), 7, dtype=np.uint8)
+    args = A.RenderArgs(5, 48, 32, frame.ctypes.data_as(C.POINTER(C.c_uint8)), C.pointer(s.c))
+    lib.render_task(C.byref(args))                   # direct call
+    bad = pt.host.render_frame_legacy(s, 48, 32)     # pool path (the harness starts from zeros)
+    print("SURVIVED", int((frame == 7).all()), int(bad.any()), lib.ptgpu_last_error().decode())
+    del os.environ["PTGPU_BOUNCES"]
+    again = pt.host.render_frame_legacy(s, 48, 32)
+    print("RECOVERED", int(np.array_equal(again, good)))
+"""
+
+
+def test_legacy_error_policy_abort_by_default_zero_on_request(gpu):
+    """A legacy call whose device path fails (here: a bounce limit no kernel
+    takes) aborts the process loudly by default -- the reference's void
+    functions have no way to say so -- and with PTGPU_ON_ERROR=zero writes
+    nothing, reports once on stderr and returns; the next good call works."""
+    import signal
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, PTGPU_SPP="2")
+    env.pop("PTGPU_ON_ERROR", None)
+    dead = subprocess.run([sys.executable, "-c", _ON_ERROR_CHILD], cwd=str(root), env=env,
+                          capture_output=True, text=True, timeout=300)
+    assert dead.returncode == -signal.SIGABRT, (dead.returncode, dead.stderr[-400:])
+    assert "SURVIVED" not in dead.stdout and "no CPU renderer to fall back to" in dead.stderr
+    alive = subprocess.run([sys.executable, "-c", _ON_ERROR_CHILD], cwd=str(root),
+                           env=dict(env, PTGPU_ON_ERROR="zero"), capture_output=True, text=True, timeout=300)
+    assert alive.returncode == 0, alive.stderr[-400:]
+    survived = [ln for ln in alive.stdout.splitlines() if ln.startswith("SURVIVED")][0].split(None, 3)
+    assert survived[1] == "1" and survived[2] == "0" and "max_bounces" in survived[3]
+    assert "RECOVERED 1" in alive.stdout
+    assert alive.stderr.count("PTGPU_ON_ERROR=zero") == 1       # said once, though two calls failed
+
+
 def test_render_task_called_directly_renders_one_row(gpu, oracle):
     A = gpu._abi
     with gpu.HostScene(1) as s:
