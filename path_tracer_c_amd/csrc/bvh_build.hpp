@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -340,6 +341,19 @@ inline BvhHost build_bvh(const F4 *geom, uint32_t n_obj, const float *corners = 
             b.hi[a] = std::nextafter((float)(c[a] + pad), std::numeric_limits<float>::infinity());
             finite = std::isfinite(c[a]) && std::isfinite(b.lo[a]) && std::isfinite(b.hi[a]);
         }
+        // (experiment knob, DESIGN.md 4.1: what closing the in-plane limit would cost the
+        // hierarchy -- PTGPU_TRI_BOX_RADII=k boxes a triangle by k bounding radii instead
+        // of by its vertices' extent; unset = the shipped boxes)
+        static const double tri_box_radii = [] {
+            const char *e = std::getenv("PTGPU_TRI_BOX_RADII");
+            return e != nullptr ? std::atof(e) : 0.0;
+        }();
+        if (finite && tri_box_radii > 0.0 && std::signbit(g.w)) {
+            for (int a = 0; a < 3; ++a) {
+                b.lo[a] = (float)(c[a] - tri_box_radii * r * 1.001);
+                b.hi[a] = (float)(c[a] + tri_box_radii * r * 1.001);
+            }
+        } else
         if (finite && corners != nullptr && corners[6 * (size_t)i] <= corners[6 * (size_t)i + 3]) {
             // the exact test accepts points of the triangle only (up to its own
             // rounding, ~1e-6 of the coordinates): pad by 1e-3 of the largest

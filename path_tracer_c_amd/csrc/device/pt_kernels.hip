@@ -1169,6 +1169,19 @@ extern "C" int ptgpu_debug_stamps(unsigned long long out[8], int reset) {
 }
 #endif
 
+#if defined(PT_SCAN_AUDIT) && !defined(PT_FAST_MATH)
+extern "C" int ptgpu_debug_scan_audit(unsigned long long out[8], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_audit), sizeof(unsigned long long) * 8) != hipSuccess)
+        return -1;
+    if (reset) {
+        unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_scan_audit), zero, sizeof zero) != hipSuccess)
+            return -1;
+    }
+    return 0;
+}
+#endif
+
 #if defined(PT_BVH_PROFILE) && !defined(PT_FAST_MATH)
 extern "C" int ptgpu_debug_bvh_profile(unsigned long long out[12], int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_profile), sizeof(unsigned long long) * 12) != hipSuccess)

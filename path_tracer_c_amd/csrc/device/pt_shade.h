@@ -184,6 +184,68 @@ struct PathState {
     bool parked;    // path ended, waiting for the settle stage
 };
 
+// Diagnostic build only (make EXTRA_HIPFLAGS=-DPT_SCAN_AUDIT; tools/inplane_audit.py): every ray a
+// culling scan (screened / hierarchy) has answered is put through the plain scan of src/ray.c:12-65
+// as well, and for every triangle the conservative screen would cull the audit asks how close the
+// ray was to the regime in which the reference's triangle test stops being geometry (DESIGN.md
+// 4.1, "in-plane rays"):
+//   [0] rays audited                      [1] rays whose culling-scan hit differs from the plain scan's
+//   [2] (ray, triangle) pairs the screen culls
+//   [3] ... of those, ray within 1e-3 rad of the triangle's plane and passing within 3 bounding radii
+//   [4] ... of those culled pairs, the reference's own test reports a hit (noise hit, culled)
+//   [5] ... and that hit is nearer than the ray's accepted hit (it would have changed the answer)
+// Summed into device words no kernel reads.  Never in the shipped library.
+#if defined(PT_SCAN_AUDIT) && !defined(PT_FAST_MATH)
+__device__ unsigned long long g_scan_audit[8];
+__device__ __forceinline__ void audit_add(int slot, bool flag) {
+    const unsigned long long m = __ballot(flag);
+    if (m != 0ull && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(true)) - 1))
+        atomicAdd(&g_scan_audit[slot], (unsigned long long)__popcll(m));
+}
+__device__ __forceinline__ void audit_ray(const SceneRecords &rec, V3 o, V3 d, Hit got, bool active) {
+    if (!__any(active))
+        return;
+    Hit plain = Hit{-1.0f, -1};
+    if (active)
+        plain = closest_hit(rec, o, d);
+    audit_add(0, active);
+    audit_add(1, active && (plain.object != got.object ||
+                            __builtin_bit_cast(uint32_t, plain.distance) != __builtin_bit_cast(uint32_t, got.distance)));
+    uint32_t culled = 0, inplane = 0, noise = 0, nearer = 0;
+    if (active && !direction_is_not_unit(d)) {
+        for (uint32_t i = 0; i < rec.n_obj; ++i) {
+            const F4 g = rec.geom[i];
+            if (!is_triangle_record(g) || screen_keep(g, o, d))
+                continue;
+            ++culled;
+            const uint32_t k = rec.link[i];
+            const V3 n = xyz(rec.tri[4 * k + 3]);
+            const V3 dp = xyz(g) - o;
+            const float along = dot(dp, d);
+            const V3 off = dp - d * along;
+            const float r2 = __builtin_fabsf(g.w);
+            if (__builtin_fabsf(dot(n, d)) < 1.0e-3f && dot(off, off) <= 9.0f * r2)
+                ++inplane;
+            float dist = 0.0f;
+            if (ray_triangle(o, d, xyz(rec.tri[4 * k + 0]), xyz(rec.tri[4 * k + 1]), xyz(rec.tri[4 * k + 2]), dist)) {
+                ++noise;
+                if (got.object < 0 || dist < got.distance)
+                    ++nearer;
+            }
+        }
+    }
+    // (called from divergent code: every lane adds for itself)
+    if (culled)
+        atomicAdd(&g_scan_audit[2], (unsigned long long)culled);
+    if (inplane)
+        atomicAdd(&g_scan_audit[3], (unsigned long long)inplane);
+    if (noise)
+        atomicAdd(&g_scan_audit[4], (unsigned long long)noise);
+    if (nearer)
+        atomicAdd(&g_scan_audit[5], (unsigned long long)nearer);
+}
+#endif
+
 // kScan: 0 plain linear scan, 1 screened linear scan, 2 BVH scan.
 template <int kScan>
 __device__ __forceinline__ Hit scan_scene(const SceneRecords &rec, V3 o, V3 d,
@@ -207,6 +269,10 @@ advance_path(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
              Hit h_known = Hit{-1.0f, -1}) {
     PT_STAMP(stamp0);
     const Hit h = known ? h_known : scan_scene<kScan>(rec, p.o, p.d, queue);
+#if defined(PT_SCAN_AUDIT) && !defined(PT_FAST_MATH)
+    if (kScan != 0) // (all lanes that are here hold a live ray)
+        audit_ray(rec, p.o, p.d, h, true);
+#endif
     PT_STAMP(stamp1);
     PT_STAMP_ADD(p.t_scan, stamp1, stamp0);
     if (h.distance < 0.0f) { // miss: this level returns the sky colour
