@@ -144,12 +144,17 @@ extern "C" {
                                          sequentially rounded arithmetic.  Same
                                          algorithm, same random stream; the frame
                                          agrees with the exact one to a stated
-                                         tolerance (>= 99.8 % of bytes within +-1,
-                                         RMSE <= 0.5 of an 8-bit level, measured
-                                         99.99 % / 0.13 on configuration 2), not to
-                                         the bit; within the mode the scheduling
-                                         flags change nothing.  Also accepted in
-                                         the scan_flags of the trace_rays calls */
+                                         tolerance (>= 99.9 % of bytes within +-1
+                                         at 256 spp, RMSE <= 0.5 of an 8-bit level;
+                                         measured 99.993 % / 0.11 on configuration
+                                         2, 99.956 % / 0.39 on configuration 5 --
+                                         1000 small spheres, where every bounce
+                                         multiplies a last-bit difference by ~100;
+                                         16-spp frames, where one sample is 16
+                                         levels: >= 99.5 %), not to the bit;
+                                         within the mode the scheduling flags
+                                         change nothing.  Also accepted in the
+                                         scan_flags of the trace_rays calls */
 #define PTGPU_FLAG_GLSL_SEMANTICS 0x2000u /* NOT scheduling only -- render by the
                                          rules of the reference's OTHER renderer,
                                          its OpenGL fragment shader

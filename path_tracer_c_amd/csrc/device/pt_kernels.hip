@@ -180,7 +180,7 @@ __device__ __forceinline__ PixelSite pixel_site(const LaunchArgs &a, uint32_t j)
     ps.out_pixel = (uint64_t)(a.compact ? lrow : grow) * W + sx;
     const float fw = (float)a.framew, fh = (float)a.frameh;
     const float aspect = fw / fh;
-#if defined(PT_FAST_MATH)
+#if defined(PT_FUSE)
     const float x = mul_add((float)sx / fw, 2.0f, -1.0f);
     const float y = -mul_add((float)grow / fh, 2.0f, -1.0f);
 #else

@@ -37,7 +37,7 @@ __device__ __forceinline__ V3 rand_unit_sphere(uint32_t &state) {
     float ry = ptgpu_u32_to_unit(state);
     state = ptgpu_xorshift32(state);
     float rz = ptgpu_u32_to_unit(state);
-#if defined(PT_FAST_MATH)
+#if defined(PT_FUSE)
     V3 cube = madd(V3{rx, ry, rz}, 2.0f, splat(-1.0f));
 #else
     V3 cube = V3{rx, ry, rz} * 2.0f - splat(1.0f);
@@ -55,7 +55,7 @@ struct Bounce {
 
 // origin of a child ray: point + direction * 0.001 (src/renderer.c:49,66)
 __device__ __forceinline__ V3 ray_origin(V3 point, V3 direction) {
-#if defined(PT_FAST_MATH)
+#if defined(PT_FUSE)
     return madd(direction, kRayOffset, point);
 #else
     return point + direction * kRayOffset;
@@ -91,7 +91,7 @@ __device__ __forceinline__ V3 shade_level(const F4 m0, const F4 m1, V3 child) {
     V3 refl = via_reflection ? child : splat(0.0f);
     V3 trans = via_reflection ? splat(0.0f) : child;
     V3 li = lerp(refl, trans, t);
-#if defined(PT_FAST_MATH)
+#if defined(PT_FUSE)
     return madd(li, xyz(m0), xyz(m1));
 #else
     return xyz(m1) + li * xyz(m0);
@@ -130,7 +130,7 @@ template <> struct Branches<true> {
 // (src/renderer.c:72-73)
 __device__ __forceinline__ V3 shade_level_both(const F4 m0, const F4 m1, V3 refl, V3 trans) {
     V3 li = lerp(refl, trans, m1.w);
-#if defined(PT_FAST_MATH)
+#if defined(PT_FUSE)
     return madd(li, xyz(m0), xyz(m1));
 #else
     return xyz(m1) + li * xyz(m0);

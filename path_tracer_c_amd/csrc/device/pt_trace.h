@@ -50,7 +50,7 @@ PT_HD bool is_triangle_record(const F4 &g) {
 // glms_ray_sphere for a unit direction; `r2` is radius*radius.
 // Returns false when there is no root or both roots are behind the origin.
 PT_HD bool ray_sphere(V3 o, V3 d, V3 c, float r2, float &t1, float &t2) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(PT_FAST_SPHERE)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PT_FAST_SPHERE) && !defined(PT_X_SPHERE)
     // Tolerance mode: the reference's formulation -- remedy term, roots as q and
     // c/q -- with fused multiply-adds and v_sqrt_f32 / v_rcp_f32 as they come.
     // (The 17-FLOP discriminant b^2 - (|dp|^2 - r^2) was tried first.  It
@@ -66,11 +66,28 @@ PT_HD bool ray_sphere(V3 o, V3 d, V3 c, float r2, float &t1, float &t2) {
     // in the last bits of this value, so it is rounded exactly as the
     // reference rounds it -- otherwise a few per cent of all paths through such
     // a scene take a different, if equally valid, course.
+    //
+    // The remedy term and the discriminant are rounded as the reference rounds
+    // them too (round 3).  For a sphere many radii away, dp - d * b takes
+    // numbers of the size of the distance down to the size of the radius, and
+    // the discriminant's last bits -- which root distance comes out -- are
+    // those of whichever sequence of roundings was used.  On configuration 5
+    // (radius-0.3 spheres up to 60 units away, every bounce multiplying a
+    // direction difference by ~100) the fused sequence ALONE put 0.09 % of the
+    // frame's bytes more than one level from the exact frame; everything else
+    // the mode changes together 0.014 %, a single fused multiply-add (the hit
+    // point) 0.003 % (tools/fast_math_parity.py on builds with one group of
+    // changes at a time, -DPT_X_DOT / _MADD / _SPHERE, -DPT_FAST_MINIMAL).
+    // Sequential here: 0.044 % -- inside SURVEY 8(c)'s 99.9 % -- for 7 more
+    // instructions per test (configuration 2: 48.2 -> 51.2 ms).  Switching by
+    // distance (fused within 16 radii) was measured too: 0.077 % and 52.1 ms,
+    // worse on both counts.  What stays cheap: v_sqrt_f32 and v_rcp_f32 as
+    // they come, and the root ordering by min / max.
     const V3 dp = c - o;
-    const float b = dot(d, dp);
+    const float b = dot_seq(d, dp);
     const float cc = dot_seq(dp, dp) - r2;
-    const V3 perp = madd(d, -b, dp);
-    const float disc = r2 - dot(perp, perp);
+    const V3 perp = dp - d * b;
+    const float disc = r2 - dot_seq(perp, perp);
     if (disc < 0.0f)
         return false;
     const float s = __builtin_amdgcn_sqrtf(disc);
@@ -81,13 +98,17 @@ PT_HD bool ray_sphere(V3 o, V3 d, V3 c, float r2, float &t1, float &t2) {
     return !(t2 < 0.0f);
 #else
     V3 dp = c - o;
-    float ddp = dot(d, dp);
-    float dpp = dot(dp, dp);
+    float ddp = dot_seq(d, dp);
+    float dpp = dot_seq(dp, dp);
     dp = dp - d * ddp; // remedy term: component of dp orthogonal to d
-    float dscr = r2 - dot(dp, dp);
+    float dscr = r2 - dot_seq(dp, dp);
     if (dscr < 0.0f)
         return false;
+#if defined(PT_X_SPHERE) && defined(__HIP_DEVICE_COMPILE__)
+    dscr = sqrt_core(dscr >= 0x1.0p-96f ? dscr : 0x1.0p-96f); // (experiment: the exact root)
+#else
     dscr = sqrt_rn(dscr);
+#endif
     float q = (ddp >= 0.0f) ? (ddp + dscr) : (ddp - dscr);
     float a = q;
     float b = (dpp - r2) / q;
@@ -891,7 +912,10 @@ PT_HD Surface surface_at(const SceneRecords &rec, V3 o, V3 d, Hit h) {
     const F4 g = rec.geom[h.object];
     const uint32_t meta = rec.meta[h.object];
     s.material = meta & kMetaMaterialMask;
-#if defined(PT_FAST_MATH)
+#if defined(PT_FAST_MINIMAL) && PT_FAST_MINIMAL == 1
+    s.point = V3{__builtin_fmaf(d.x, h.distance, o.x), __builtin_fmaf(d.y, h.distance, o.y),
+                 __builtin_fmaf(d.z, h.distance, o.z)}; // the experiment's one fused operation
+#elif defined(PT_FUSE)
     s.point = madd(d, h.distance, o);
 #else
     s.point = d * h.distance + o;

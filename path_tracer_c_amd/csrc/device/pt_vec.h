@@ -41,10 +41,18 @@
 #endif
 // (the two halves of the mode can be switched off one by one when looking for
 // the source of a difference: -DPT_EXACT_SPHERE, -DPT_EXACT_RECIP)
-#if defined(PT_FAST_MATH) && !defined(PT_EXACT_SPHERE)
+// (-DPT_FAST_MINIMAL: an experiment, never shipped -- the tolerance build's
+// namespace and plumbing with the EXACT arithmetic everywhere except one fused
+// multiply-add, the hit point of surface_at (pt_trace.h): how far does the
+// smallest possible perturbation move configuration 5's frame?  ptgpu.h,
+// PTGPU_FLAG_FAST_MATH, has the answer.)
+#if defined(PT_FAST_MATH) && !defined(PT_FAST_MINIMAL)
+#define PT_FUSE 1
+#endif
+#if defined(PT_FUSE) && !defined(PT_EXACT_SPHERE)
 #define PT_FAST_SPHERE 1
 #endif
-#if defined(PT_FAST_MATH) && !defined(PT_EXACT_RECIP)
+#if defined(PT_FUSE) && !defined(PT_EXACT_RECIP)
 #define PT_FAST_RECIP 1
 #endif
 #ifdef PT_FAST_MATH
@@ -72,7 +80,7 @@ PT_HD V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
 // a * b + c: two roundings in the exact build (as the reference's separate
 // operations round), one fused multiply-add in the tolerance build.
 PT_HD float mul_add(float a, float b, float c) {
-#if defined(PT_FAST_MATH) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(PT_FUSE) && defined(__HIP_DEVICE_COMPILE__) && !defined(PT_X_MADD)
     return __builtin_fmaf(a, b, c);
 #else
     return a * b + c;
@@ -87,7 +95,7 @@ PT_HD V3 madd(V3 a, V3 s, V3 b) { // a * s + b, component-wise
 
 // x*x' + y*y' + z*z', summed left to right (glms_vec3_dot).
 PT_HD float dot(V3 a, V3 b) {
-#if defined(PT_FAST_MATH) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(PT_FUSE) && defined(__HIP_DEVICE_COMPILE__) && !defined(PT_X_DOT)
     return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x));
 #else
     return a.x * b.x + a.y * b.y + a.z * b.z;
@@ -100,7 +108,7 @@ PT_HD float dot(V3 a, V3 b) {
 PT_HD float dot_seq(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
 PT_HD V3 cross(V3 a, V3 b) {
-#if defined(PT_FAST_MATH) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(PT_FUSE) && defined(__HIP_DEVICE_COMPILE__) && !defined(PT_X_DOT)
     return V3{__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
               __builtin_fmaf(a.x, b.y, -(a.y * b.x))};
 #else
@@ -240,7 +248,7 @@ PT_HD V3 normalize_dir(V3 a) {
 
 // glms_vec3_lerp: from + (to - from) * t, not clamped.
 PT_HD V3 lerp(V3 from, V3 to, float t) {
-#if defined(PT_FAST_MATH) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(PT_FUSE) && defined(__HIP_DEVICE_COMPILE__)
     return madd(to - from, t, from);
 #else
     return from + (to - from) * t;
@@ -260,7 +268,10 @@ PT_HD V3 clamp01(V3 v) {
 // glms_vec3_reflect: v - n * (2 * dot(v, n)).
 PT_HD V3 reflect(V3 v, V3 n) {
     float twice = 2.0f * dot(v, n);
-#if defined(PT_FAST_MATH) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(PT_FAST_MINIMAL) && PT_FAST_MINIMAL == 2 && defined(__HIP_DEVICE_COMPILE__)
+    return V3{__builtin_fmaf(n.x, -twice, v.x), __builtin_fmaf(n.y, -twice, v.y),
+              __builtin_fmaf(n.z, -twice, v.z)}; // (the experiment's one fused operation, variant 2)
+#elif defined(PT_FUSE) && defined(__HIP_DEVICE_COMPILE__)
     return madd(n, -twice, v);
 #else
     return v - n * twice;
@@ -271,7 +282,7 @@ PT_HD V3 reflect(V3 v, V3 n) {
 PT_HD bool refract(V3 v, V3 n, float eta, V3 &out) {
     float ndi = dot(n, v);
     float eni = eta * ndi;
-#if defined(PT_FAST_MATH) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(PT_FUSE) && defined(__HIP_DEVICE_COMPILE__)
     float k = __builtin_fmaf(eni, eni, __builtin_fmaf(-eta, eta, 1.0f));
 #else
     float k = 1.0f - eta * eta + eni * eni;
@@ -281,7 +292,7 @@ PT_HD bool refract(V3 v, V3 n, float eta, V3 &out) {
         return false;
     }
     float along = eni + sqrt_rn(k);
-#if defined(PT_FAST_MATH) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(PT_FUSE) && defined(__HIP_DEVICE_COMPILE__)
     out = madd(n, -along, v * eta);
 #else
     out = v * eta - n * along;

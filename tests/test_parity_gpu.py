@@ -2019,7 +2019,7 @@ def test_fast_math_frames_are_within_the_stated_tolerance(gpu, torch_cuda, name,
 def test_fast_math_frame_of_configuration_5_is_within_the_stated_tolerance(gpu, torch_cuda):
     """Configuration 5 at full size (1000 small spheres: a bounce off a radius-0.3
     sphere multiplies a direction error by ~100, so a last-bit difference can be
-    another path three bounces later): >= 99.8 % of the bytes within +-1 of the
+    another path three bounces later): >= 99.9 % of the bytes within +-1 of the
     exact frame, RMSE <= 0.5 level, no brightness shift -- and far closer to it
     than the exact frame of another seed is (3.45 levels).  With the 17-FLOP
     discriminant the mode was first built with, 2 % of the bytes were off by more
@@ -2031,7 +2031,9 @@ def test_fast_math_frame_of_configuration_5_is_within_the_stated_tolerance(gpu, 
     assert _rmse(fast, exact) <= 0.5
     assert _rmse(fast, exact) <= 0.25 * _rmse(other, exact)
     assert abs((fast - exact).mean()) <= 0.02
-    assert np.mean(np.abs(fast - exact) <= 1) >= 0.998
+    # SURVEY.md 8(c)'s bar (round 3; 99.8 % before the sphere test's remedy term and
+    # discriminant were rounded as the reference rounds them: measured 99.956 %)
+    assert np.mean(np.abs(fast - exact) <= 1) >= 0.999
 
 
 def test_fast_math_is_the_same_picture_whatever_the_schedule(gpu, torch_cuda):
