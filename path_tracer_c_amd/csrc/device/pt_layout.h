@@ -42,6 +42,22 @@ struct F4 { // plain 16-byte record usable on host and device
     float x, y, z, w;
 };
 
+// What the shader-rules mode (PTGPU_FLAG_GLSL_SEMANTICS, pt_glsl.hip) needs to cull with
+// the hierarchy: its sphere test is a plain quadratic whose rounding error grows with the
+// distance to the sphere (|error of r^2 - perp^2| <~ 12 eps (D^2 + r^2)), so the walk pads
+// the boxes by what that error can reach for the given ray -- which takes the extent and
+// the radii of the scene WITHOUT the few spheres that dwarf it (a radius-1000 ground
+// under unit-size objects); those are tested for every ray instead.
+constexpr uint32_t kGlslBigMax = 8;
+struct GlslCull {
+    float lo[3], hi[3];       // box around every bounded object that is not in `big`
+    float r2_min, r2_max;     // squared radii of the spheres that are not in `big` (0, 0: none)
+    uint32_t big[kGlslBigMax]; // spheres larger than the rest of the scene
+    uint32_t n_big;
+    uint32_t last_scanned;    // the object the shader's two-array scan visits last
+                              // (last triangle, else last sphere; 0xFFFFFFFF: empty scene)
+};
+
 // One device-resident scene: a single allocation, records at these offsets.
 struct SceneDesc {
     const F4 *geom;       // n_obj
@@ -71,6 +87,7 @@ struct SceneDesc {
     uint32_t branching; // some material has 0 < transparency < 1
     float sky[3];
     uint32_t last_sphere; // highest index of a sphere, 0xFFFFFFFF: no sphere
+    GlslCull glsl;
 };
 
 // Bytes of the scene blob = LDS bytes its copy needs (16-byte records first,

@@ -354,6 +354,73 @@ int ptgpu_set_device(int device) {
 // ---------------------------------------------------------------------------
 // scene residency
 // ---------------------------------------------------------------------------
+namespace {
+// pt_layout.h, GlslCull: set the spheres that dwarf the rest of the scene apart,
+// then record box and radii of the rest.
+void fill_glsl_cull(const pt::F4 *geom, uint32_t n_obj, pt::GlslCull *out) {
+    std::memset(out, 0, sizeof *out);
+    out->last_scanned = 0xFFFFFFFFu;
+    uint32_t last_tri = 0xFFFFFFFFu, last_sph = 0xFFFFFFFFu;
+    std::vector<uint32_t> spheres;
+    for (uint32_t i = 0; i < n_obj; ++i) {
+        const bool tri = std::signbit(geom[i].w);
+        (tri ? last_tri : last_sph) = i;
+        const float r2 = std::fabs(geom[i].w);
+        if (!tri && std::isfinite(r2) && std::isfinite(geom[i].x) && std::isfinite(geom[i].y) &&
+            std::isfinite(geom[i].z))
+            spheres.push_back(i);
+    }
+    out->last_scanned = last_tri != 0xFFFFFFFFu ? last_tri : last_sph;
+    std::sort(spheres.begin(), spheres.end(),
+              [&](uint32_t a, uint32_t b) { return geom[a].w > geom[b].w; });
+    auto box_without = [&](size_t skip, double lo[3], double hi[3]) {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::numeric_limits<double>::infinity();
+            hi[a] = -lo[a];
+        }
+        std::vector<char> big(n_obj, 0);
+        for (size_t k = 0; k < skip; ++k)
+            big[spheres[k]] = 1;
+        for (uint32_t i = 0; i < n_obj; ++i) {
+            const double r = std::sqrt((double)std::fabs(geom[i].w));
+            const double c[3] = {geom[i].x, geom[i].y, geom[i].z};
+            if (big[i] || !std::isfinite(r) || !std::isfinite(c[0] + c[1] + c[2]))
+                continue; // (objects without a finite box are tested for every ray anyway)
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = std::min(lo[a], c[a] - r);
+                hi[a] = std::max(hi[a], c[a] + r);
+            }
+        }
+    };
+    // the largest gap in the sorted radii, if it is a real one (8 x) and at most
+    // kGlslBigMax spheres lie above it: C5's ground, the five walls of a Cornell box
+    size_t n_big = 0;
+    double widest = 64.0; // (squared radii)
+    for (size_t k = 1; k <= pt::kGlslBigMax && k < spheres.size(); ++k) {
+        const double above = geom[spheres[k - 1]].w, below = geom[spheres[k]].w;
+        const double ratio = below > 0.0 ? above / below : (above > 0.0 ? 1e300 : 0.0);
+        if (ratio > widest) {
+            widest = ratio;
+            n_big = k;
+        }
+    }
+    double lo[3], hi[3];
+    box_without(n_big, lo, hi);
+    out->n_big = (uint32_t)n_big;
+    for (size_t k = 0; k < n_big; ++k)
+        out->big[k] = spheres[k];
+    for (int a = 0; a < 3; ++a) {
+        // (outward in binary32; an empty rest leaves an inverted box: no padding needed)
+        out->lo[a] = std::nextafter((float)lo[a], -std::numeric_limits<float>::infinity());
+        out->hi[a] = std::nextafter((float)hi[a], std::numeric_limits<float>::infinity());
+    }
+    if (n_big < spheres.size()) {
+        out->r2_max = std::nextafter(geom[spheres[n_big]].w, std::numeric_limits<float>::infinity());
+        out->r2_min = geom[spheres.back()].w;
+    }
+}
+} // namespace
+
 int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
     if (host == nullptr || out == nullptr)
         return fail(PTGPU_ERR_INVALID, "scene or out pointer is NULL");
@@ -543,6 +610,7 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
     for (uint32_t i = 0; i < n_obj; ++i)
         if (host->objects[i].tag == 0)
             h->desc.last_sphere = i;
+    fill_glsl_cull(geom, n_obj, &h->desc.glsl);
     {
         std::lock_guard<std::mutex> guard(g_choice_mutex);
         auto known = g_choices.find(h->content_hash);

@@ -955,6 +955,30 @@ def test_primary_hits_are_shared_in_the_stream_kernel_and_accounted(gpu, oracle)
     assert st_shared.rays - st_shared.scans == w * h * spp
 
 
+def test_two_paths_per_lane_experiment_renders_the_same_frame(gpu, torch_cuda, oracle, monkeypatch):
+    """pt_duokernel (PTGPU_DUO=1; round 3's measured negative): the stream
+    kernel with two paths per lane picks the same samples apart differently and must store the
+    same bytes -- configuration 5's scene with and without the primary-hit table, against the
+    stream kernel and the oracle, ray counts included."""
+    A = gpu._abi
+    w, h = 320, 180
+    kw = dict(spp=8, max_bounces=8, seed=9)
+    with gpu.HostScene(5) as s, gpu.DeviceScene(s) as d:
+        ref = _oracle_rows(oracle, s, w, h, (0, 60, 179), **kw)
+        for flags in (A.FLAG_SAMPLE_QUEUE | A.FLAG_SCAN_BVH, A.FLAG_SAMPLE_QUEUE | A.FLAG_SCAN_BVH | A.FLAG_NO_PRIMARY_SHARE):
+            frames, rays = {}, {}
+            for duo in ("0", "1"):
+                monkeypatch.setenv("PTGPU_DUO", duo)
+                gpu.host.reset_stats()
+                frames[duo] = render_device(gpu, torch_cuda, d, w, h, flags=flags, **kw)
+                st = gpu.host.read_stats()
+                rays[duo] = (st.rays, st.scans, st.samples)
+            assert np.array_equal(frames["0"], frames["1"]), hex(flags)
+            assert rays["0"] == rays["1"], (hex(flags), rays)
+            for y, row in ref.items():
+                assert np.array_equal(frames["1"][y], row), (hex(flags), y)
+
+
 def test_cached_primary_hits_follow_the_view(gpu, oracle, torch_cuda):
     """The primary-hit table is kept between calls of one view (progressive
     passes) and redone when the scene, the camera or the row set changes."""
@@ -2421,10 +2445,77 @@ def test_glsl_semantics_randomised_scenes_match_the_shader_oracle(gpu, oracle):
             b = int(rng.integers(0, 7))
             seed = int(rng.integers(0, 2**31))
             fov = float(np.float32(rng.choice([np.pi / 2, np.pi / 2, 0.3, 1.2, 2.8])))
-            got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=seed, fov_rad=fov,
-                                   flags=gpu._abi.FLAG_GLSL_SEMANTICS)
             ref = oracle.glsl_render_rows(s, w, h, spp=spp, max_bounces=b, seed=seed, fov_rad=fov)[0]
-            assert np.array_equal(got, ref), (trial, w, h, spp, b, seed, fov, s.counts())
+            # the shader's own scan of every object, and (round 3) the same closest hits through
+            # the hierarchy with boxes padded for the shader's noisier sphere test
+            A = gpu._abi
+            forms = [A.FLAG_SCAN_PLAIN] + ([A.FLAG_SCAN_BVH] if s.num_objects >= 64 else []) + [0]
+            for f in forms:
+                got = gpu.render_frame(s, w, h, spp=spp, max_bounces=b, seed=seed, fov_rad=fov,
+                                       flags=A.FLAG_GLSL_SEMANTICS | f)
+                assert np.array_equal(got, ref), (trial, hex(f), w, h, spp, b, seed, fov, s.counts())
+
+
+def test_glsl_semantics_hierarchy_walk_equals_the_shaders_own_scan(gpu, torch_cuda):
+    """Round 3: the shader-rules mode finds its closest hits through the hierarchy on scenes of
+    >= 96 objects.  The shader's sphere test is a plain quadratic whose error grows with the
+    distance (it "hits" beside far-away small spheres, at a noisy distance), so the walk pads its
+    boxes by what that error can reach and prunes by distance only beyond the noise
+    (csrc/device/pt_glsl.hip).  Whole frames, hierarchy against the shader's own scan of every
+    object, byte for byte and ray for ray: configuration 5's 1001 spheres, a height field with
+    spheres, and scenes built to stress the bound -- radii over six decades, zero radius
+    included, small spheres hundreds of units away, spheres that dwarf the rest."""
+    A = gpu._abi
+    rng = np.random.default_rng(20263)
+
+    def both(s, w, h, **kw):
+        out = []
+        with gpu.DeviceScene(s) as d:
+            for f in (A.FLAG_SCAN_PLAIN, A.FLAG_SCAN_BVH):
+                gpu.host.reset_stats()
+                frame = render_device(gpu, torch_cuda, d, w, h, flags=A.FLAG_GLSL_SEMANTICS | f, **kw)
+                out.append((frame, gpu.host.read_stats().rays))
+        assert out[0][1] == out[1][1], ("rays", out[0][1], out[1][1])
+        assert np.array_equal(out[0][0], out[1][0])
+
+    with gpu.HostScene(5) as s:
+        both(s, 480, 270, spp=8, max_bounces=8, seed=3)
+    # the regime the padding exists for: tiny spheres packed closely (tight boxes) a long way
+    # off, seen through a narrow field of view so that most rays pass between them -- the
+    # shader's quadratic "hits" such a sphere from up to ~20 radii beside it (without the
+    # padding, -DPT_GLSL_NO_PAD, this frame differs in dozens of pixels)
+    for dist, radius in ((300.0, 0.01), (3000.0, 0.05), (40.0, 0.002)):
+        with gpu.HostScene() as s:
+            s.set_sky(0.2, 0.3, 0.5)
+            m = [s.add_material((0.9, 0.5, 0.3), roughness=0.5, emission_color=(1, 1, 1), emission_strength=2.0),
+                 s.add_material((0.3, 0.9, 0.5), roughness=0.0)]
+            step = dist * 0.0027
+            for i in range(20):
+                for j in range(15):
+                    c = ((i - 9.5) * step + rng.uniform(-0.3, 0.3) * step, (j - 7) * step + rng.uniform(-0.3, 0.3) * step,
+                         dist + rng.uniform(-1, 1) * step)
+                    s.add_sphere(c, radius * float(rng.uniform(0.5, 2.0)), m[(i + j) % 2])
+            both(s, 320, 180, spp=2, max_bounces=3, seed=5, fov_rad=0.06)
+    for trial in range(max(6, int(os.environ.get("PT_FUZZ_TRIALS", "40")) // 8)):
+        with gpu.HostScene() as s:
+            s.set_sky(0.6, 0.7, 0.9)
+            mats = [s.add_material((0.8, 0.7, 0.6), roughness=float(rng.uniform(0, 1))),
+                    s.add_material((0.9, 0.9, 0.9), roughness=0.0),
+                    s.add_material((1, 1, 1), roughness=0.0, transparency=1.0, refractive_index=1.5),
+                    s.add_material((0.5, 0.5, 0.9), roughness=0.3, emission_color=(1, 1, 1), emission_strength=3.0)]
+            scale = float(10 ** rng.uniform(-1, 2))
+            n = int(rng.integers(120, 400))
+            for _ in range(n):
+                c = rng.normal(0, 1, 3) * scale * float(10 ** rng.uniform(0, 2.5)) + np.array([0, 0, 3 * scale])
+                r = 0.0 if rng.integers(0, 12) == 0 else scale * float(10 ** rng.uniform(-3, 1))
+                s.add_sphere(tuple(c), r, mats[int(rng.integers(0, 4))])
+            for _ in range(int(rng.integers(0, 4))):      # spheres that dwarf the rest
+                s.add_sphere(tuple(rng.normal(0, 1, 3) * scale * 2000), scale * float(rng.uniform(1000, 3000)), mats[0])
+            for _ in range(int(rng.integers(0, 30))):
+                c = rng.normal(0, 1, 3) * scale * 5 + np.array([0, 0, 6 * scale])
+                e1, e2 = rng.normal(0, 1, 3) * scale, rng.normal(0, 1, 3) * scale
+                s.add_triangle(tuple(c), tuple(c + e1), tuple(c + e2), mats[int(rng.integers(0, 4))])
+            both(s, 160, 90, spp=4, max_bounces=int(rng.integers(1, 8)), seed=trial)
 
 
 def test_fast_math_randomised_scenes_are_the_same_picture_in_every_scan_form(gpu):
