@@ -171,9 +171,17 @@ extern "C" {
                                          accumulator, sample_offset 0), at most
                                          PTGPU_MAX_BOUNCES_TREE bounces.  Checked
                                          against a CPU restatement of the shader
-                                         (oracle/pt_glsl.c): bit-equal where no
-                                         random number is consumed, to a stated
-                                         tolerance otherwise (log / cos) */
+                                         (oracle/pt_glsl.c): bit-equal, through a
+                                         shared specification of log / cos
+                                         (ptgpu_glsl_math.h).  Scenes of >= 96
+                                         objects find their closest hits through
+                                         the hierarchy (boxes padded for the
+                                         shader's own, noisier sphere test;
+                                         configuration 5 at 32 spp 337 -> 46 ms);
+                                         PTGPU_FLAG_SCAN_PLAIN keeps the shader's
+                                         scan of every object, _SCAN_BVH forces
+                                         the hierarchy from 64 objects: same
+                                         frame */
 
 /* limits */
 #define PTGPU_MAX_BOUNCES_PATH 62 /* non-branching kernel (LDS material stack) */
