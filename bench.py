@@ -317,7 +317,7 @@ def main():
     if world > 1:
         my_kernel = sum(a.elapsed_time(b) for a, b in kernel_ms) / max(1, len(kernel_ms))
         my_gather = sum(a.elapsed_time(b) for a, b in gather_ms) / max(1, len(gather_ms))
-        per_rank = tiles.scaling_report(my_kernel, my_gather, h, w, tile)
+        per_rank = tiles.scaling_report(my_kernel, my_gather, h, w, tile, device=red)
 
     if rank == 0:
         rays_per_step = rays / args.steps

@@ -193,7 +193,10 @@ struct Builder {
     // or when the centres cannot be separated, the median along the widest
     // axis (by index if all centres coincide), which bounds the depth.
     static constexpr uint32_t kSahLevels = 24;
-    static constexpr int kBins = 16;
+#ifndef PT_BVH_BINS
+#define PT_BVH_BINS 16
+#endif
+    static constexpr int kBins = PT_BVH_BINS;
     uint32_t choose_split(uint32_t begin, uint32_t end, uint32_t level) {
         const uint32_t n = end - begin;
         float clo[3], chi[3];

@@ -120,21 +120,26 @@ def gather_bytes(height: int, width: int, world: int, tile_rows: int) -> dict:
 
 
 def scaling_report(kernel_ms: float, gather_ms: float, height: int, width: int,
-                   tile_rows: int, group=None) -> dict:
+                   tile_rows: int, group=None, device=None) -> dict:
     """Per-rank figures that make a scaling curve explainable (all ranks call
     this; every rank gets the same dict): each rank's kernel time per frame
     (HIP events around its render launches), the time of the gather as each
     rank saw it, the imbalance max / mean of the kernel times, the bytes the
-    gather moved, and how many ranks the process group really has."""
+    gather moved, and how many ranks the process group really has.  One
+    all_gather of two float64 per rank, on `device` ("cuda" under the nccl
+    backend = RCCL, "cpu" under gloo)."""
+    import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    mine = (float(kernel_ms), float(gather_ms))
     if world > 1:
-        both = [None] * world
-        dist.all_gather_object(both, mine, group=group)
+        mine = torch.tensor([float(kernel_ms), float(gather_ms)], dtype=torch.float64,
+                            device=device or "cpu")
+        both = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine, group=group)
+        both = [tuple(float(x) for x in t.tolist()) for t in both]
     else:
-        both = [mine]
+        both = [(float(kernel_ms), float(gather_ms))]
     kernel = [b[0] for b in both]
     gather = [b[1] for b in both]
     mean = sum(kernel) / len(kernel)
