@@ -554,7 +554,9 @@ hipError_t launch_glsl(const LaunchArgs &a, hipStream_t stream) {
         return hipSuccess;
     const uint32_t block = 64;
     const uint32_t grid = (uint32_t)((npix + block - 1) / block);
-    if (a.screened == 2u && a.scene.bvh_nodes != nullptr) {
+    // (this mode has two scan forms: the shader's own and the hierarchy; a scene whose
+    // default-mode choice is the screened linear scan takes the hierarchy if it has one)
+    if (a.screened != 0u && a.scene.bvh_nodes != nullptr) {
         const size_t lds = (size_t)4 * 64u * (kScreenQueue + a.scene.bvh_depth + 2u);
         if (lds > 64u * 1024u) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pt_glsl_kernel<true>),
