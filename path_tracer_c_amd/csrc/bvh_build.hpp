@@ -325,7 +325,14 @@ struct Builder {
 // with corners[6 i] <= corners[6 i + 3] its own axis-aligned extent
 // {lo.xyz, hi.xyz} -- a triangle's vertices span much less than its bounding
 // sphere -- which is then padded and intersected with the sphere's box.
-inline BvhHost build_bvh(const F4 *geom, uint32_t n_obj, const float *corners = nullptr) {
+// `apart` (optional, n_obj flags): objects kept out of the hierarchy and tested
+// for every ray like the ones without a finite box -- the few spheres that
+// dwarf the rest of a scene (a radius-1000 ground under unit-size objects), which
+// nearly every ray meets anyway: in the tree such a sphere is a leaf at the root
+// that every walk must visit, queue and test before it knows the distance that
+// prunes everything else (round 3, csrc/ptgpu_abi.hip: spheres_that_dwarf_the_rest).
+inline BvhHost build_bvh(const F4 *geom, uint32_t n_obj, const float *corners = nullptr,
+                         const char *apart = nullptr) {
     using bvh_detail::Box;
     BvhHost out;
     std::vector<Box> boxes;
@@ -379,7 +386,7 @@ inline BvhHost build_bvh(const F4 *geom, uint32_t n_obj, const float *corners = 
                 }
             }
         }
-        if (!finite) {
+        if (!finite || (apart != nullptr && apart[i])) {
             out.unbounded.push_back(i);
             continue;
         }

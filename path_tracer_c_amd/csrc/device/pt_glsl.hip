@@ -299,13 +299,11 @@ __device__ __forceinline__ void g_walk(const SceneDesc &sc, V3 o, V3 d, float in
         }
         wr = queue;
     };
-    // objects without a finite box, and the spheres that dwarf the scene
+    // objects outside the hierarchy: no finite box, or spheres that dwarf the scene
     for (uint32_t k = 0; k < sc.n_unbounded; ++k) {
         const uint32_t idx = sc.bvh_unbounded[k];
         g_candidate(sc, o, d, idx, sc.geom[idx], after_pos, u);
     }
-    for (uint32_t k = 0; k < gc.n_big; ++k)
-        g_candidate(sc, o, d, gc.big[k], sc.geom[gc.big[k]], after_pos, u);
 
     constexpr uint32_t kDone = 0xFFFFFFFFu;
     uint32_t cur = sc.bvh_root;

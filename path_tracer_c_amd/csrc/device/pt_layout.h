@@ -47,13 +47,12 @@ struct F4 { // plain 16-byte record usable on host and device
 // distance to the sphere (|error of r^2 - perp^2| <~ 12 eps (D^2 + r^2)), so the walk pads
 // the boxes by what that error can reach for the given ray -- which takes the extent and
 // the radii of the scene WITHOUT the few spheres that dwarf it (a radius-1000 ground
-// under unit-size objects); those are tested for every ray instead.
+// under unit-size objects); those are outside the hierarchy and tested for every ray
+// in every mode (bvh_build.hpp, `apart`).
 constexpr uint32_t kGlslBigMax = 8;
 struct GlslCull {
-    float lo[3], hi[3];       // box around every bounded object that is not in `big`
-    float r2_min, r2_max;     // squared radii of the spheres that are not in `big` (0, 0: none)
-    uint32_t big[kGlslBigMax]; // spheres larger than the rest of the scene
-    uint32_t n_big;
+    float lo[3], hi[3];       // box around every object of the hierarchy
+    float r2_min, r2_max;     // squared radii of its spheres (0, 0: none)
     uint32_t last_scanned;    // the object the shader's two-array scan visits last
                               // (last triangle, else last sphere; 0xFFFFFFFF: empty scene)
 };

@@ -355,45 +355,21 @@ int ptgpu_set_device(int device) {
 // scene residency
 // ---------------------------------------------------------------------------
 namespace {
-// pt_layout.h, GlslCull: set the spheres that dwarf the rest of the scene apart,
-// then record box and radii of the rest.
-void fill_glsl_cull(const pt::F4 *geom, uint32_t n_obj, pt::GlslCull *out) {
-    std::memset(out, 0, sizeof *out);
-    out->last_scanned = 0xFFFFFFFFu;
-    uint32_t last_tri = 0xFFFFFFFFu, last_sph = 0xFFFFFFFFu;
+// The spheres that dwarf the rest of a scene: those above the largest gap in the
+// sorted radii, if it is a real one (8 x) and at most kGlslBigMax spheres lie
+// above it -- configuration 5's ground, the five walls of a Cornell box.  They
+// are kept out of the hierarchy and tested for every ray (bvh_build.hpp), and the
+// shader-rules mode sizes its box padding by the scene without them (GlslCull).
+void spheres_that_dwarf_the_rest(const pt::F4 *geom, uint32_t n_obj, std::vector<char> *out) {
     std::vector<uint32_t> spheres;
     for (uint32_t i = 0; i < n_obj; ++i) {
-        const bool tri = std::signbit(geom[i].w);
-        (tri ? last_tri : last_sph) = i;
-        const float r2 = std::fabs(geom[i].w);
-        if (!tri && std::isfinite(r2) && std::isfinite(geom[i].x) && std::isfinite(geom[i].y) &&
-            std::isfinite(geom[i].z))
+        const float r2 = geom[i].w;
+        if (!std::signbit(r2) && std::isfinite(r2) && std::isfinite(geom[i].x) &&
+            std::isfinite(geom[i].y) && std::isfinite(geom[i].z))
             spheres.push_back(i);
     }
-    out->last_scanned = last_tri != 0xFFFFFFFFu ? last_tri : last_sph;
     std::sort(spheres.begin(), spheres.end(),
               [&](uint32_t a, uint32_t b) { return geom[a].w > geom[b].w; });
-    auto box_without = [&](size_t skip, double lo[3], double hi[3]) {
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = std::numeric_limits<double>::infinity();
-            hi[a] = -lo[a];
-        }
-        std::vector<char> big(n_obj, 0);
-        for (size_t k = 0; k < skip; ++k)
-            big[spheres[k]] = 1;
-        for (uint32_t i = 0; i < n_obj; ++i) {
-            const double r = std::sqrt((double)std::fabs(geom[i].w));
-            const double c[3] = {geom[i].x, geom[i].y, geom[i].z};
-            if (big[i] || !std::isfinite(r) || !std::isfinite(c[0] + c[1] + c[2]))
-                continue; // (objects without a finite box are tested for every ray anyway)
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = std::min(lo[a], c[a] - r);
-                hi[a] = std::max(hi[a], c[a] + r);
-            }
-        }
-    };
-    // the largest gap in the sorted radii, if it is a real one (8 x) and at most
-    // kGlslBigMax spheres lie above it: C5's ground, the five walls of a Cornell box
     size_t n_big = 0;
     double widest = 64.0; // (squared radii)
     for (size_t k = 1; k <= pt::kGlslBigMax && k < spheres.size(); ++k) {
@@ -404,19 +380,50 @@ void fill_glsl_cull(const pt::F4 *geom, uint32_t n_obj, pt::GlslCull *out) {
             n_big = k;
         }
     }
-    double lo[3], hi[3];
-    box_without(n_big, lo, hi);
-    out->n_big = (uint32_t)n_big;
+    out->assign(n_obj, 0);
     for (size_t k = 0; k < n_big; ++k)
-        out->big[k] = spheres[k];
+        (*out)[spheres[k]] = 1;
+}
+
+// pt_layout.h, GlslCull: box and radii of the scene without the objects in `apart`.
+void fill_glsl_cull(const pt::F4 *geom, uint32_t n_obj, const std::vector<char> &apart,
+                    pt::GlslCull *out) {
+    std::memset(out, 0, sizeof *out);
+    out->last_scanned = 0xFFFFFFFFu;
+    uint32_t last_tri = 0xFFFFFFFFu, last_sph = 0xFFFFFFFFu;
+    double lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = std::numeric_limits<double>::infinity();
+        hi[a] = -lo[a];
+    }
+    float r2_min = std::numeric_limits<float>::infinity(), r2_max = 0.0f;
+    bool any_sphere = false;
+    for (uint32_t i = 0; i < n_obj; ++i) {
+        const bool tri = std::signbit(geom[i].w);
+        (tri ? last_tri : last_sph) = i;
+        const double r = std::sqrt((double)std::fabs(geom[i].w));
+        const double c[3] = {geom[i].x, geom[i].y, geom[i].z};
+        if (apart[i] || !std::isfinite(r) || !std::isfinite(c[0] + c[1] + c[2]))
+            continue; // (tested for every ray: no box to pad for them)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], c[a] - r);
+            hi[a] = std::max(hi[a], c[a] + r);
+        }
+        if (!tri) {
+            any_sphere = true;
+            r2_min = std::min(r2_min, geom[i].w);
+            r2_max = std::max(r2_max, geom[i].w);
+        }
+    }
+    out->last_scanned = last_tri != 0xFFFFFFFFu ? last_tri : last_sph;
     for (int a = 0; a < 3; ++a) {
         // (outward in binary32; an empty rest leaves an inverted box: no padding needed)
         out->lo[a] = std::nextafter((float)lo[a], -std::numeric_limits<float>::infinity());
         out->hi[a] = std::nextafter((float)hi[a], std::numeric_limits<float>::infinity());
     }
-    if (n_big < spheres.size()) {
-        out->r2_max = std::nextafter(geom[spheres[n_big]].w, std::numeric_limits<float>::infinity());
-        out->r2_min = geom[spheres.back()].w;
+    if (any_sphere) {
+        out->r2_max = std::nextafter(r2_max, std::numeric_limits<float>::infinity());
+        out->r2_min = r2_min;
     }
 }
 } // namespace
@@ -534,6 +541,8 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
     h->desc.n_unbounded = 0;
     h->desc.bvh_root = pt::kBvhLeafBit;
     h->desc.bvh_depth = 0;
+    std::vector<char> apart;
+    spheres_that_dwarf_the_rest(geom, n_obj, &apart);
     if (n_obj >= kBvhMinObjects) {
         // triangles: their vertices' extent (much tighter than the box of the
         // bounding sphere the screen uses); spheres: none (lo > hi)
@@ -556,7 +565,7 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
                 ext[3] = 0.0f;
             }
         }
-        const pt::BvhHost bvh = pt::build_bvh(geom, n_obj, corners.data());
+        const pt::BvhHost bvh = pt::build_bvh(geom, n_obj, corners.data(), apart.data());
         // A leaf visit fetches kLeafMax slots of `order` and of the geometry
         // copied into leaf order, whatever the leaf's count (one memory round
         // trip instead of two per object): both arrays are padded accordingly.
@@ -610,7 +619,7 @@ int ptgpu_scene_upload(const scene *host, ptgpu_scene **out) {
     for (uint32_t i = 0; i < n_obj; ++i)
         if (host->objects[i].tag == 0)
             h->desc.last_sphere = i;
-    fill_glsl_cull(geom, n_obj, &h->desc.glsl);
+    fill_glsl_cull(geom, n_obj, apart, &h->desc.glsl);
     {
         std::lock_guard<std::mutex> guard(g_choice_mutex);
         auto known = g_choices.find(h->content_hash);
