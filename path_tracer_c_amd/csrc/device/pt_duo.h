@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_DUO_
     auto shade_stage = [&]() {
         const bool c0 = ready0();
         const bool c1 = !c0 && ready1();
-        if (!__any(c0 || c1))
+        if (!pt_any(c0 || c1))
             return;
         PT_BVH_COUNT(6, c0 || c1);
         V3 o = duo_pick(c1, s0.o, s1.o), d = duo_pick(c1, s0.d, s1.d);
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_DUO_
     auto settle_stage = [&]() {
         const bool c0 = s0.st == duo::kParked;
         const bool c1 = !c0 && s1.st == duo::kParked;
-        if (!__any(c0 || c1))
+        if (!pt_any(c0 || c1))
             return;
         if (c0 || c1) {
             PathState p;
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_DUO_
         bool is_free = c0 || c1;
         bool got = false;
         uint32_t sample = 0, j = 0;
-        unsigned long long free_mask = __ballot(is_free);
+        unsigned long long free_mask = pt_ballot(is_free);
         if (free_mask == 0ull || cursor.dry)
             return;
         while (free_mask != 0ull && !cursor.dry) {
@@ -272,9 +272,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_DUO_
                 sample = smp;
                 j = jj;
             }
-            free_mask = __ballot(is_free);
+            free_mask = pt_ballot(is_free);
         }
-        if (!__any(got))
+        if (!pt_any(got))
             return;
         const bool g0 = got && c0, g1 = got && c1;
         uint32_t *const queue = duo_pick(c1, queue0, queue1);
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_DUO_
         {
             const bool c0 = is_inner(s0.cur);
             const bool c1 = !c0 && is_inner(s1.cur);
-            if (__any(c0 || c1)) {
+            if (pt_any(c0 || c1)) {
                 const V3 o = duo_pick(c1, s0.o, s1.o);
                 const V3 inv = duo_pick(c1, s0.inv, s1.inv);
                 const float best = duo_pick(c1, s0.u.best, s1.u.best);
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_DUO_
                 };
                 for (uint32_t step = 0; step < a.walk_budget; ++step) {
                     const bool inner = mine && is_inner(cur);
-                    if (!__any(inner))
+                    if (!pt_any(inner))
                         break;
                     PT_BVH_COUNT(0, inner);
                     if (inner) {
@@ -380,9 +380,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_DUO_
             const bool l0 = is_leaf(s0.cur) && !pressing0();
             const bool l1 = is_leaf(s1.cur) && !pressing1();
             const bool c0 = l0, c1 = !l0 && l1;
-            const unsigned long long leaf_mask = __ballot(c0 || c1);
+            const unsigned long long leaf_mask = pt_ballot(c0 || c1);
             const bool do_leaves = (uint32_t)__popcll(leaf_mask) >= a.leaf_lanes ||
-                                   !__any(is_inner(s0.cur) || is_inner(s1.cur));
+                                   !pt_any(is_inner(s0.cur) || is_inner(s1.cur));
             if (do_leaves && leaf_mask != 0ull) {
                 PT_BVH_COUNT(2, c0 || c1);
                 uint32_t cur = duo_pick(c1, s0.cur, s1.cur);
@@ -409,9 +409,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_DUO_
             const bool press0 = pressing0(), press1 = pressing1();
             const bool can_step = is_inner(s0.cur) || is_inner(s1.cur) ||
                                   (is_leaf(s0.cur) && !press0) || (is_leaf(s1.cur) && !press1);
-            if (__any(press0 || press1) ||
-                (uint32_t)__popcll(__ballot(p0 || p1)) >= a.resolve_lanes ||
-                (__any(p0 || p1) && !__any(can_step))) {
+            if (pt_any(press0 || press1) ||
+                (uint32_t)__popcll(pt_ballot(p0 || p1)) >= a.resolve_lanes ||
+                (pt_any(p0 || p1) && !pt_any(can_step))) {
                 const bool c1 = press1 || (!p0 && p1);
                 const bool c0 = !c1 && p0;
                 const V3 o = duo_pick(c1, s0.o, s1.o), d = duo_pick(c1, s0.d, s1.d);
@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_DUO_
                 uint32_t *const queue = duo_pick(c1, queue0, queue1);
                 uint32_t *const wr = duo_pick(c1, s0.wr, s1.wr);
                 const bool mine = c0 || c1;
-                for (uint32_t *rd = queue; __any(mine && rd < wr); rd += kStride) {
+                for (uint32_t *rd = queue; pt_any(mine && rd < wr); rd += kStride) {
                     PT_BVH_COUNT(4, mine && rd < wr);
                     if (mine && rd < wr) {
                         const uint32_t idx = *rd;
@@ -439,10 +439,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_DUO_
         const bool idle_free = !cursor.dry;
         const bool wait0 = r0 || s0.st == duo::kParked || (s0.st == duo::kFree && idle_free);
         const bool wait1 = r1 || s1.st == duo::kParked || (s1.st == duo::kFree && idle_free);
-        const unsigned long long walking = __ballot(walking0 || walking1);
+        const unsigned long long walking = pt_ballot(walking0 || walking1);
         const bool full_service =
-            walking == 0ull || (uint32_t)__popcll(__ballot(wait0 || wait1)) >= a.settle_lanes;
-        if (!full_service && (uint32_t)__popcll(__ballot(r0 || r1)) >= a.shade_lanes) {
+            walking == 0ull || (uint32_t)__popcll(pt_ballot(wait0 || wait1)) >= a.settle_lanes;
+        if (!full_service && (uint32_t)__popcll(pt_ballot(r0 || r1)) >= a.shade_lanes) {
             shade_stage();
             continue;
         }
@@ -456,10 +456,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_DUO_
                 // one slot per stage
                 const bool again0 = ready0() || s0.st == duo::kParked || (s0.st == duo::kFree && !cursor.dry);
                 const bool again1 = ready1() || s1.st == duo::kParked || (s1.st == duo::kFree && !cursor.dry);
-                if ((uint32_t)__popcll(__ballot(again0 || again1)) < a.reshade_lanes)
+                if ((uint32_t)__popcll(pt_ballot(again0 || again1)) < a.reshade_lanes)
                     break;
             }
-            if (__ballot(s0.st != duo::kFree || s1.st != duo::kFree) == 0ull)
+            if (pt_ballot(s0.st != duo::kFree || s1.st != duo::kFree) == 0ull)
                 break; // pool dry and every slot idle
             continue;
         }

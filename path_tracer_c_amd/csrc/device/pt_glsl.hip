@@ -291,7 +291,7 @@ __device__ __forceinline__ void g_walk(const SceneDesc &sc, V3 o, V3 d, float in
     };
     uint32_t *wr = queue;
     auto resolve = [&]() {
-        for (uint32_t *rd = queue; __any(rd < wr); rd += stride) {
+        for (uint32_t *rd = queue; pt_any(rd < wr); rd += stride) {
             if (rd < wr) {
                 const uint32_t idx = *rd;
                 g_candidate(sc, o, d, idx, sc.geom[idx], after_pos, u);
@@ -308,8 +308,8 @@ __device__ __forceinline__ void g_walk(const SceneDesc &sc, V3 o, V3 d, float in
     constexpr uint32_t kDone = 0xFFFFFFFFu;
     uint32_t cur = sc.bvh_root;
     uint32_t *sp = stack;
-    while (__any(cur != kDone)) {
-        while (__any(cur != kDone && !(cur & kLeafRef))) {
+    while (pt_any(cur != kDone)) {
+        while (pt_any(cur != kDone && !(cur & kLeafRef))) {
             if (cur != kDone && !(cur & kLeafRef)) {
                 const F4 a = sc.bvh_nodes[2u * cur + 0u];
                 const F4 b = sc.bvh_nodes[2u * cur + 1u];
@@ -362,7 +362,7 @@ __device__ __forceinline__ void g_walk(const SceneDesc &sc, V3 o, V3 d, float in
                 cur = kDone;
             }
         }
-        if (__any(wr > queue)) // (as early as possible: the best distance prunes the walk)
+        if (pt_any(wr > queue)) // (as early as possible: the best distance prunes the walk)
             resolve();
     }
     resolve();
@@ -383,7 +383,7 @@ __device__ __forceinline__ GHit g_trace_bvh(const SceneDesc &sc, V3 o, V3 d, uin
     const uint32_t last_pos =
         last == 0xFFFFFFFFu ? 0u
                             : ((__builtin_bit_cast(uint32_t, sc.geom[last].w) & 0x80000000u) ? sc.n_obj : 0u) + last + 1u;
-    for (int walk = 0; walk < 2 && __any(walking); ++walk) {
+    for (int walk = 0; walk < 2 && pt_any(walking); ++walk) {
         if (walking)
             g_walk(sc, o, d, inv_dd, queue, stack, stride, after_pos, u);
         // the answer lies beyond a degenerate result only if a positive one came before it
@@ -409,7 +409,7 @@ __device__ __forceinline__ GHit g_trace_bvh(const SceneDesc &sc, V3 o, V3 d, uin
     if (pos != 0u)
         object = pos - 1u >= sc.n_obj ? pos - 1u - sc.n_obj : pos - 1u;
     GHit h = g_surface(sc, o, d, distance, object);
-    if (__any(odd)) {
+    if (pt_any(odd)) {
         if (odd)
             h = g_trace(sc, o, d);
     }

@@ -217,7 +217,7 @@ __device__ __forceinline__ void store_rgb8(uint8_t *frame, V3 sum, float samples
     const uint32_t packed = pack_rgb8(sum, samples);
     const uint64_t first = __shfl(out_pixel, 0, 64);
     const bool wave_dense =
-        __all(valid && out_pixel == first + lane) &&
+        pt_all(valid && out_pixel == first + lane) &&
         ((reinterpret_cast<uintptr_t>(frame + 3u * first) & 3u) == 0u);
     // dword k of the wave's 192 bytes = bytes 4k..4k+3 = tail of pixel 4k/3
     // and head of the next one
@@ -519,16 +519,16 @@ __global__ void __launch_bounds__(1024)
 
     for (;;) {
         // ---- refill free lanes from the wave's chunk (ballot + prefix sum) ----
-        unsigned long long free_mask = __ballot(!have);
+        unsigned long long free_mask = pt_ballot(!have);
         while (free_mask != 0ull && !cursor.dry) {
             uint32_t sample, j;
             if (take_task(cursor, a, chunk_counter, free_mask, !have, lane, sample, j) && j < npix) {
                 have = true;
                 start_path(a, j, sample, p, out_index);
             }
-            free_mask = __ballot(!have);
+            free_mask = pt_ballot(!have);
         }
-        if (__ballot(have) == 0ull)
+        if (pt_ballot(have) == 0ull)
             break; // pool dry and every lane idle
 
         // ---- one recursion level for the live lanes -------------------------------
@@ -669,11 +669,11 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PT_ST
                 atomicAdd(&g_bvh_profile[8], 1ull);
 #endif
         }
-        const unsigned long long walking = __ballot(st == kWalk);
+        const unsigned long long walking = pt_ballot(st == kWalk);
         const unsigned long long waiting =
-            __ballot(st == kHit || st == kParked || (st == kFree && !cursor.dry));
+            pt_ballot(st == kHit || st == kParked || (st == kFree && !cursor.dry));
         const bool full_service = walking == 0ull || (uint32_t)__popcll(waiting) >= a.settle_lanes;
-        if (!full_service && (uint32_t)__popcll(__ballot(st == kHit)) >= a.shade_lanes) {
+        if (!full_service && (uint32_t)__popcll(pt_ballot(st == kHit)) >= a.shade_lanes) {
             // ---- quick stage: finished walks are shaded and their next rays start,
             // which is most of what waits (3.4 segments per path on C5); ended
             // paths and free lanes wait for a full service
@@ -710,7 +710,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PT_ST
                 PT_STAMP(sv2);
                 PT_STAMP_ADD(t_settle, sv2, sv1);
                 // refill free lanes from the wave's chunk (as pt_samplekernel does)
-                unsigned long long free_mask = __ballot(st == kFree);
+                unsigned long long free_mask = pt_ballot(st == kFree);
                 while (free_mask != 0ull && !cursor.dry) {
                     uint32_t sample, j;
                     if (take_task(cursor, a, chunk_counter, free_mask, st == kFree, lane, sample, j) &&
@@ -726,16 +726,16 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PT_ST
                             ++shared;
                         }
                     }
-                    free_mask = __ballot(st == kFree);
+                    free_mask = pt_ballot(st == kFree);
                 }
                 PT_STAMP(sv3);
                 PT_STAMP_ADD(t_refill, sv3, sv2);
                 if (a.primary_hits == nullptr ||
-                    (uint32_t)__popcll(__ballot(st == kHit)) < a.reshade_lanes)
+                    (uint32_t)__popcll(pt_ballot(st == kHit)) < a.reshade_lanes)
                     break;
             }
             begin_walks();
-            if (__ballot(st != kFree) == 0ull)
+            if (pt_ballot(st != kFree) == 0ull)
                 break; // pool dry and every lane idle
             continue;
         }

@@ -41,9 +41,9 @@ run_paths(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
     }
 
     PT_STAMP(begin);
-    while (__any(p.live || p.parked)) {
+    while (pt_any(p.live || p.parked)) {
         ++iters;
-        const bool all_at_start = a.share_primary && !__any(p.live && p.depth != 0u);
+        const bool all_at_start = a.share_primary && !pt_any(p.live && p.depth != 0u);
         if (p.live) {
             ++rays;
             if (!all_at_start)
@@ -123,9 +123,9 @@ run_paths_split(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
         bool open = p.live; // this lane traces a sample in this round, not complete yet
         V3 sample = splat(0.0f);
         for (;;) {
-            while (__any(p.live)) {
+            while (pt_any(p.live)) {
                 ++iters;
-                const bool all_at_start = a.share_primary && !__any(p.live && p.depth != 0u);
+                const bool all_at_start = a.share_primary && !pt_any(p.live && p.depth != 0u);
                 if (p.live) {
                     ++rays;
                     if (!all_at_start)
@@ -140,7 +140,7 @@ run_paths_split(const SceneRecords &rec, const LaunchArgs &a, uint16_t *stack,
                 open = false;
                 ++samples_done;
             }
-            if (!kTree || !__any(p.live))
+            if (!kTree || !pt_any(p.live))
                 break;
         }
         // the pixel's first lane adds samples round*k .. round*k + k-1, in order

@@ -198,12 +198,12 @@ struct PathState {
 #if defined(PT_SCAN_AUDIT) && !defined(PT_FAST_MATH)
 __device__ unsigned long long g_scan_audit[8];
 __device__ __forceinline__ void audit_add(int slot, bool flag) {
-    const unsigned long long m = __ballot(flag);
-    if (m != 0ull && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(true)) - 1))
+    const unsigned long long m = pt_ballot(flag);
+    if (m != 0ull && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)pt_ballot(true)) - 1))
         atomicAdd(&g_scan_audit[slot], (unsigned long long)__popcll(m));
 }
 __device__ __forceinline__ void audit_ray(const SceneRecords &rec, V3 o, V3 d, Hit got, bool active) {
-    if (!__any(active))
+    if (!pt_any(active))
         return;
     Hit plain = Hit{-1.0f, -1};
     if (active)
@@ -399,8 +399,8 @@ __device__ __forceinline__ bool settle_path(const SceneRecords &rec, const Launc
 // Wave-uniform decision of the settle stage (see run_paths).
 __device__ __forceinline__ bool settle_now(bool live, bool parked,
                                            uint32_t settle_lanes) {
-    const unsigned long long parked_mask = __ballot(parked);
-    const unsigned long long live_mask = __ballot(live);
+    const unsigned long long parked_mask = pt_ballot(parked);
+    const unsigned long long live_mask = pt_ballot(live);
     return parked_mask != 0ull &&
            (live_mask == 0ull || (uint32_t)__popcll(parked_mask) >= settle_lanes);
 }

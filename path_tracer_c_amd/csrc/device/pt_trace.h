@@ -186,8 +186,8 @@ PT_HD void test_object(const SceneRecords &rec, V3 o, V3 d, uint32_t i,
             const bool far = has && best > 0.0f &&
                              (cc > 0.0f ? (ddp < 0.0f || (gap >= 0.0f && gap * gap >= dscr))
                                         : (gap >= 0.0f || dscr >= gap * gap));
-            const unsigned long long has_mask = __ballot(has), far_mask = __ballot(far);
-            if (has_mask != 0ull && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(true)) - 1)) {
+            const unsigned long long has_mask = pt_ballot(has), far_mask = pt_ballot(far);
+            if (has_mask != 0ull && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)pt_ballot(true)) - 1)) {
                 atomicAdd(&g_farreject[0], 1ull);
                 if (far_mask == has_mask)
                     atomicAdd(&g_farreject[1], 1ull);
@@ -362,7 +362,7 @@ __device__ __forceinline__ Hit closest_hit_screened(const SceneRecords &rec,
     uint32_t *wr = first; // next free entry of this lane's queue
 
     auto resolve = [&]() {
-        for (uint32_t *rd = first; __any(rd < wr); rd += q.stride) {
+        for (uint32_t *rd = first; pt_any(rd < wr); rd += q.stride) {
             if (rd < wr) {
                 const uint32_t idx = *rd;
                 test_object(rec, o, d, idx, rec.geom[idx], h);
@@ -388,7 +388,7 @@ __device__ __forceinline__ Hit closest_hit_screened(const SceneRecords &rec,
 #pragma unroll
         for (uint32_t j = 0; j < kScreenBlock; ++j)
             push(screen_keep(g[j], o, d), i + j);
-        if (__any(wr > nearly_full))
+        if (pt_any(wr > nearly_full))
             resolve();
     }
     for (; i < n; ++i)
@@ -396,7 +396,7 @@ __device__ __forceinline__ Hit closest_hit_screened(const SceneRecords &rec,
     resolve();
     // (the screen is geometry for a unit direction; any other gets the plain scan)
     const bool odd = direction_is_not_unit(d);
-    if (__any(odd)) {
+    if (pt_any(odd)) {
         if (odd)
             h = closest_hit(rec, o, d);
     }
@@ -515,7 +515,7 @@ __device__ __forceinline__ bool box_crossed(const F4 lo, const F4 hi, V3 inv, V3
     // infinite `enter` or `leave` (a product that overflows: box coordinates are
     // finite or point away from the box, and an infinite 1 / d was dropped above)
     // makes the slack infinite and every comparison false: the box is kept.
-    const bool missed = (leave + slack < fmaxf(enter, 0.0f)) | (enter - slack > best);
+    const bool missed = (leave + slack < fmaxf(enter, 0.0f)) || (enter - slack > best);
     return !missed;
 }
 
@@ -561,7 +561,7 @@ PT_HD void test_object_unordered(const SceneRecords &rec, V3 o, V3 d, uint32_t i
 __device__ unsigned long long g_bvh_profile[12];
 #define PT_BVH_COUNT(slot, active)                                             \
     do {                                                                       \
-        prof[slot] += (uint32_t)__popcll(__ballot(active));                    \
+        prof[slot] += (uint32_t)__popcll(pt_ballot(active));                    \
         prof[(slot) + 1] += 1u;                                                \
     } while (0)
 #else
@@ -572,7 +572,7 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
                                                const ScreenQueue q) {
 #ifdef PT_BVH_PROFILE
     uint32_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    prof[6] = (uint32_t)__popcll(__ballot(true));
+    prof[6] = (uint32_t)__popcll(pt_ballot(true));
     prof[7] = 1u;
 #endif
     UnorderedBest u;
@@ -590,7 +590,7 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
     uint32_t *const nearly_full = first + (PT_BVH_RESOLVE_AT) * q.stride;
 
     auto resolve = [&]() {
-        for (uint32_t *rd = first; __any(rd < wr); rd += q.stride) {
+        for (uint32_t *rd = first; pt_any(rd < wr); rd += q.stride) {
             PT_BVH_COUNT(4, rd < wr);
             if (rd < wr) {
                 const uint32_t idx = *rd;
@@ -619,7 +619,7 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
     };
     constexpr uint32_t kDone = 0xFFFFFFFFu; // not a valid ref: count field would be 7
     for (int walk = 0; walk < 2; ++walk) {
-        if (!__any(walking))
+        if (!pt_any(walking))
             break;
         for (uint32_t k = 0; k < rec.n_unbounded; ++k) {
             const uint32_t idx = rec.bvh_unbounded[k];
@@ -627,16 +627,16 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
                 *wr = idx;
                 wr += q.stride;
             }
-            if (__any(wr > nearly_full))
+            if (pt_any(wr > nearly_full))
                 resolve();
         }
         uint32_t cur = walking ? rec.bvh_root : kDone;
         uint32_t *sp = q.stack; // next free stack entry of this lane
-        while (__any(cur != kDone)) {
+        while (pt_any(cur != kDone)) {
             // descend until no lane of the wave stands on an inner node: the
             // leaf code below then runs once for many lanes instead of on
             // every pass for a few
-            while (__any(cur != kDone && !(cur & kLeafRef))) {
+            while (pt_any(cur != kDone && !(cur & kLeafRef))) {
                 PT_BVH_COUNT(0, cur != kDone && !(cur & kLeafRef));
                 if (cur != kDone && !(cur & kLeafRef)) {
                     const NodeBoxes nb = load_node(rec, cur);
@@ -669,7 +669,7 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
                     cur = kDone;
                 }
             }
-            if (__any(wr > nearly_full))
+            if (pt_any(wr > nearly_full))
                 resolve();
         }
         resolve();
@@ -696,7 +696,7 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
         h.distance = -1.0f;
         h.object = -1;
     }
-    if (__any(poisoned)) {
+    if (pt_any(poisoned)) {
         if (poisoned)
             h = poisoned_hit(rec, o, d);
     }
@@ -813,10 +813,15 @@ __device__ __forceinline__ void bvh_walk_quantum(const SceneRecords &rec,
             w.cur = kBvhDone;
         }
     };
+    // (`mine` is implied wherever a walk has something to visit or to test: only a
+    // walking lane's `cur` is not kBvhDone and only its queue is not empty -- and a
+    // vote on one comparison is one instruction, where a vote on a conjunction
+    // is written out as 0 / 1 and compared again)
+    (void)mine;
     PT_QSTAMP(q_begin);
     for (uint32_t step = 0; step < inner_budget; ++step) {
-        const bool inner = mine && w.cur != kBvhDone && !(w.cur & kLeafRef);
-        if (!__any(inner))
+        const bool inner = (int32_t)w.cur >= 0; // != kBvhDone and no leaf bit
+        if (!pt_any(inner))
             break;
         PT_BVH_COUNT(0, inner);
         if (inner) {
@@ -825,24 +830,27 @@ __device__ __forceinline__ void bvh_walk_quantum(const SceneRecords &rec,
             const bool go_l = crosses(nb.l_lo, nb.l_hi, l_enter);
             const bool go_r = crosses(nb.r_lo, nb.r_hi, r_enter);
             const uint32_t l_ref = nb.l_ref, r_ref = nb.r_ref;
-            if (go_l & go_r) {
-                const bool r_first = r_enter < l_enter;
+            // (all the deciding done on the comparisons' own masks, before any
+            // branch: kept across the three-way branch the two answers were
+            // written out as 0 / 1 and compared again)
+            const bool both = go_l && go_r;
+            const bool none = !go_l && !go_r;
+            const bool r_first = go_r && (!go_l || r_enter < l_enter);
+            const uint32_t near = r_first ? r_ref : l_ref;
+            if (both) {
                 *w.sp = r_first ? l_ref : r_ref; // the farther child waits
                 w.sp += q.stride;
-                w.cur = r_first ? r_ref : l_ref;
-            } else if (go_l | go_r) {
-                w.cur = go_l ? l_ref : r_ref;
-            } else {
-                pop();
             }
+            w.cur = near;
+            if (none)
+                pop();
         }
     }
     PT_QSTAMP(q_inner);
     PT_QSTAMP_ADD(0, q_inner, q_begin);
-    const bool at_leaf = mine && w.cur != kBvhDone && (w.cur & kLeafRef);
-    const unsigned long long leaf_mask = __ballot(at_leaf);
-    const bool do_leaves = (uint32_t)__popcll(leaf_mask) >= leaf_lanes ||
-                           !__any(mine && w.cur != kBvhDone && !(w.cur & kLeafRef));
+    const bool at_leaf = w.cur != kBvhDone && (w.cur & kLeafRef);
+    const unsigned long long leaf_mask = pt_ballot(at_leaf);
+    const bool do_leaves = (uint32_t)__popcll(leaf_mask) >= leaf_lanes || !pt_any((int32_t)w.cur >= 0);
     if (do_leaves) {
         PT_BVH_COUNT(2, at_leaf);
     }
@@ -852,20 +860,19 @@ __device__ __forceinline__ void bvh_walk_quantum(const SceneRecords &rec,
     }
     PT_QSTAMP(q_leaf);
     PT_QSTAMP_ADD(1, q_leaf, q_inner);
-    const bool pending = mine && w.wr != q.slot;
-    const bool pressing = mine && (w.wr > q.slot + (kScreenQueue - kLeafSlots - 1u) * q.stride); // + one more leaf still fits
-    const bool can_step = mine && w.cur != kBvhDone;
-    if (__any(pressing) || (uint32_t)__popcll(__ballot(pending)) >= resolve_lanes ||
-        (__any(pending) && !__any(can_step))) {
-        for (uint32_t *rd = q.slot; __any(mine && rd < w.wr); rd += q.stride) {
-            PT_BVH_COUNT(4, mine && rd < w.wr);
-            if (mine && rd < w.wr) {
+    const bool pending = w.wr != q.slot;
+    const bool pressing = w.wr > q.slot + (kScreenQueue - kLeafSlots - 1u) * q.stride; // + one more leaf still fits
+    const bool can_step = w.cur != kBvhDone;
+    if (pt_any(pressing) || (uint32_t)__popcll(pt_ballot(pending)) >= resolve_lanes ||
+        (pt_any(pending) && !pt_any(can_step))) {
+        for (uint32_t *rd = q.slot; pt_any(rd < w.wr); rd += q.stride) {
+            PT_BVH_COUNT(4, rd < w.wr);
+            if (rd < w.wr) {
                 const uint32_t idx = *rd;
                 test_object_unordered(rec, o, d, idx, rec.geom[idx], w.u);
             }
         }
-        if (mine)
-            w.wr = q.slot;
+        w.wr = q.slot;
     }
     PT_QSTAMP(q_exact);
     PT_QSTAMP_ADD(2, q_exact, q_leaf);

@@ -22,6 +22,21 @@
 
 #define PT_HD __host__ __device__ __forceinline__
 
+// Wave-level votes on a bool.  HIP's __ballot / __any / __all take an int: a
+// predicate is first written out as 0 / 1 into a VGPR and compared again
+// (v_cndmask + v_cmp per vote; the inner-node step of the walk votes once per
+// step).  The builtin takes the condition as it is: one s_and of the
+// comparison's own mask.
+__device__ __forceinline__ unsigned long long pt_ballot(bool p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(p);
+#else
+    return p ? 1ull : 0ull; // (host pass of the same translation unit: never called)
+#endif
+}
+__device__ __forceinline__ bool pt_any(bool p) { return pt_ballot(p) != 0ull; }
+__device__ __forceinline__ bool pt_all(bool p) { return pt_ballot(!p) == 0ull; }
+
 // The device code is compiled twice (Makefile): as namespace `pt` under the
 // bit-exact contract described above, and -- with -DPT_FAST_MATH
 // -DPT_NS=pt_fast -- as namespace `pt_fast`, the opt-in tolerance mode behind
