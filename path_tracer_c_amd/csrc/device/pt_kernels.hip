@@ -661,19 +661,35 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PT_ST
     };
 
     for (;;) {
-        if (st == kWalk && bvh_walk_idle(w.queue, walk)) {
-            if (bvh_walk_finish(w.rec, w.queue, p.o, p.d, walk, hit))
-                st = kHit;
+        // ---- walk quanta, until a shading stage or a service is due -----------------
+        // (a loop of its own: a quantum changes the walk's fields only, and as one arm
+        // of the outer loop it made the compiler carry the lane's WHOLE state -- ray,
+        // stream state, 1 / d ... -- in two register sets and move one into the
+        // other, ~54 v_mov, on every trip through a quantum)
+        bool full_service;
+        for (;;) {
+            if (st == kWalk && bvh_walk_idle(w.queue, walk)) {
+                if (bvh_walk_finish(w.rec, w.queue, p.o, p.d, walk, hit))
+                    st = kHit;
 #ifdef PT_BVH_PROFILE
-            else
-                atomicAdd(&g_bvh_profile[8], 1ull);
+                else
+                    atomicAdd(&g_bvh_profile[8], 1ull);
 #endif
+            }
+            const unsigned long long walking = pt_ballot(st == kWalk);
+            const unsigned long long waiting =
+                pt_ballot(st == kHit || st == kParked || (st == kFree && !cursor.dry));
+            full_service = walking == 0ull || (uint32_t)__popcll(waiting) >= a.settle_lanes;
+            if (full_service || (uint32_t)__popcll(pt_ballot(st == kHit)) >= a.shade_lanes)
+                break;
+            ++iters;
+            PT_STAMP(q0);
+            bvh_walk_quantum(w.rec, w.queue, p.o, p.d, st == kWalk, a.walk_budget, a.leaf_lanes,
+                             a.resolve_lanes, walk, prof);
+            PT_STAMP(q1);
+            PT_STAMP_ADD(t_walk, q1, q0);
         }
-        const unsigned long long walking = pt_ballot(st == kWalk);
-        const unsigned long long waiting =
-            pt_ballot(st == kHit || st == kParked || (st == kFree && !cursor.dry));
-        const bool full_service = walking == 0ull || (uint32_t)__popcll(waiting) >= a.settle_lanes;
-        if (!full_service && (uint32_t)__popcll(pt_ballot(st == kHit)) >= a.shade_lanes) {
+        if (!full_service) {
             // ---- quick stage: finished walks are shaded and their next rays start,
             // which is most of what waits (3.4 segments per path on C5); ended
             // paths and free lanes wait for a full service
@@ -682,9 +698,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PT_ST
             begin_walks();
             PT_STAMP(sq1);
             PT_STAMP_ADD(t_shade, sq1, sq0);
-            continue;
-        }
-        if (full_service) {
+        } else {
             // ---- service -----------------------------------------------------------
             // (twice over when the refill has handed out enough tasks that
             // start at a known primary hit: they are shaded at once instead
@@ -737,14 +751,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PT_ST
             begin_walks();
             if (pt_ballot(st != kFree) == 0ull)
                 break; // pool dry and every lane idle
-            continue;
         }
-        ++iters;
-        PT_STAMP(q0);
-        bvh_walk_quantum(w.rec, w.queue, p.o, p.d, st == kWalk, a.walk_budget, a.leaf_lanes,
-                         a.resolve_lanes, walk, prof);
-        PT_STAMP(q1);
-        PT_STAMP_ADD(t_walk, q1, q0);
     }
 #ifdef PT_STAMPS
     {
