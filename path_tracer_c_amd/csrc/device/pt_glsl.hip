@@ -286,7 +286,7 @@ __device__ __forceinline__ void g_walk(const SceneDesc &sc, V3 o, V3 d, float in
         enter = fmaxf(fmaxf(fminf(x0, x1) - pad_t.x, fminf(y0, y1) - pad_t.y), fminf(z0, z1) - pad_t.z);
         const float leave = fminf(fminf(fmaxf(x0, x1) + pad_t.x, fmaxf(y0, y1) + pad_t.y), fmaxf(z0, z1) + pad_t.z);
         const float slack = __builtin_fmaf(PT_BOX_SLACK, fabsf(enter) + fabsf(leave), slabs.slack0);
-        const bool missed = (leave + slack < fmaxf(enter, 0.0f)) | (enter - slack - noise > u.best);
+        const bool missed = (leave + slack < fmaxf(enter, 0.0f)) || (enter - slack - noise > u.best);
         return !missed;
     };
     uint32_t *wr = queue;
@@ -323,18 +323,21 @@ __device__ __forceinline__ void g_walk(const SceneDesc &sc, V3 o, V3 d, float in
                 const bool go_r = crosses(F4{half_lo(b0), half_hi(b0), half_lo(b1), 0.0f},
                                           F4{half_hi(b1), half_lo(b2), half_hi(b2), 0.0f}, r_enter);
                 const uint32_t l_ref = __builtin_bit_cast(uint32_t, a.w), r_ref = __builtin_bit_cast(uint32_t, b.w);
-                if (go_l & go_r) {
-                    const bool r_first = r_enter < l_enter;
+                const bool both = go_l && go_r;
+                const bool none = !go_l && !go_r;
+                const bool r_first = go_r && (!go_l || r_enter < l_enter);
+                if (both) {
                     *sp = r_first ? l_ref : r_ref;
                     sp += stride;
-                    cur = r_first ? r_ref : l_ref;
-                } else if (go_l | go_r) {
-                    cur = go_l ? l_ref : r_ref;
-                } else if (sp != stack) {
-                    sp -= stride;
-                    cur = *sp;
-                } else {
-                    cur = kDone;
+                }
+                cur = r_first ? r_ref : l_ref;
+                if (none) {
+                    if (sp != stack) {
+                        sp -= stride;
+                        cur = *sp;
+                    } else {
+                        cur = kDone;
+                    }
                 }
             }
         }

@@ -662,18 +662,22 @@ __device__ __forceinline__ Hit closest_hit_bvh(const SceneRecords &rec, V3 o, V3
                     const bool go_l = crosses(nb.l_lo, nb.l_hi, l_enter);
                     const bool go_r = crosses(nb.r_lo, nb.r_hi, r_enter);
                     const uint32_t l_ref = nb.l_ref, r_ref = nb.r_ref;
-                    if (go_l & go_r) {
-                        const bool r_first = r_enter < l_enter;
+                    // (decided on the comparisons' own masks before any branch: see bvh_walk_quantum)
+                    const bool both = go_l && go_r;
+                    const bool none = !go_l && !go_r;
+                    const bool r_first = go_r && (!go_l || r_enter < l_enter);
+                    if (both) {
                         *sp = r_first ? l_ref : r_ref; // the farther child waits
                         sp += q.stride;
-                        cur = r_first ? r_ref : l_ref;
-                    } else if (go_l | go_r) {
-                        cur = go_l ? l_ref : r_ref;
-                    } else if (sp != q.stack) {
-                        sp -= q.stride;
-                        cur = *sp;
-                    } else {
-                        cur = kDone;
+                    }
+                    cur = r_first ? r_ref : l_ref;
+                    if (none) {
+                        if (sp != q.stack) {
+                            sp -= q.stride;
+                            cur = *sp;
+                        } else {
+                            cur = kDone;
+                        }
                     }
                 }
             }
