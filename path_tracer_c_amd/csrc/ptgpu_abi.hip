@@ -381,6 +381,8 @@ void spheres_that_dwarf_the_rest(const pt::F4 *geom, uint32_t n_obj, std::vector
         }
     }
     out->assign(n_obj, 0);
+    if (std::getenv("PTGPU_NO_APART") != nullptr) // (experiment knob: everything bounded stays in the tree)
+        return;
     for (size_t k = 0; k < n_big; ++k)
         (*out)[spheres[k]] = 1;
 }
