@@ -177,7 +177,7 @@ extern "C" {
                                          objects find their closest hits through
                                          the hierarchy (boxes padded for the
                                          shader's own, noisier sphere test;
-                                         configuration 5 at 32 spp 337 -> 41 ms);
+                                         configuration 5 at 32 spp 337 -> 40 ms);
                                          PTGPU_FLAG_SCAN_PLAIN keeps the shader's
                                          scan of every object, _SCAN_BVH forces
                                          the hierarchy from 64 objects: same
