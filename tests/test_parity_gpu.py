@@ -955,6 +955,33 @@ def test_primary_hits_are_shared_in_the_stream_kernel_and_accounted(gpu, oracle)
     assert st_shared.rays - st_shared.scans == w * h * spp
 
 
+def test_config5_every_hierarchy_form_against_the_linear_scan_at_full_size(gpu, torch_cuda, monkeypatch):
+    """Configuration 5 at 1920x1080, 64 spp, every segment walked (447 million rays): the stream
+    kernel, the whole-walk kernels and the two-paths-per-lane experiment against the screened
+    LINEAR scan, which has no boxes to get wrong -- frames and ray counts.  This is the run that
+    found round 3's fused box test dropping boxes for rays with an exactly-zero direction
+    component: 17 of these rays, 3 pixels."""
+    A = gpu._abi
+    c = gpu.CONFIGS[5]
+    w, h = c["width"], c["height"]
+    kw = dict(spp=64, max_bounces=c["max_bounces"], seed=1)
+    share = A.FLAG_NO_PRIMARY_SHARE
+    with gpu.HostScene(5) as s, gpu.DeviceScene(s) as d:
+        def run(flags, duo="0"):
+            monkeypatch.setenv("PTGPU_DUO", duo)
+            gpu.host.reset_stats()
+            frame = render_device(gpu, torch_cuda, d, w, h, flags=flags | share, **kw)
+            return frame, gpu.host.read_stats().rays
+
+        ref, rays = run(A.FLAG_SCAN_SCREENED | A.FLAG_SAMPLE_QUEUE)
+        for name, flags, duo in (("stream", A.FLAG_SCAN_BVH | A.FLAG_SAMPLE_QUEUE, "0"),
+                                 ("whole walks", A.FLAG_SCAN_BVH | A.FLAG_SAMPLE_QUEUE | A.FLAG_WHOLE_WALKS, "0"),
+                                 ("two paths per lane", A.FLAG_SCAN_BVH | A.FLAG_SAMPLE_QUEUE, "1")):
+            got, n = run(flags, duo)
+            assert n == rays, (name, n, rays)
+            assert np.array_equal(got, ref), (name, int((got != ref).any(axis=2).sum()), "pixels differ")
+
+
 def test_two_paths_per_lane_experiment_renders_the_same_frame(gpu, torch_cuda, oracle, monkeypatch):
     """pt_duokernel (PTGPU_DUO=1; round 3's measured negative): the stream
     kernel with two paths per lane picks the same samples apart differently and must store the
