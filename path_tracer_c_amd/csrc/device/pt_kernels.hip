@@ -668,6 +668,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PT_ST
         // other, ~54 v_mov, on every trip through a quantum)
         bool full_service;
         for (;;) {
+            if (pt_any(st == kFresh))
+                begin_walks();
             if (st == kWalk && bvh_walk_idle(w.queue, walk)) {
                 if (bvh_walk_finish(w.rec, w.queue, p.o, p.d, walk, hit))
                     st = kHit;
@@ -695,7 +697,6 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PT_ST
             // paths and free lanes wait for a full service
             PT_STAMP(sq0);
             shade_hits();
-            begin_walks();
             PT_STAMP(sq1);
             PT_STAMP_ADD(t_shade, sq1, sq0);
         } else {
@@ -748,7 +749,6 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PT_ST
                     (uint32_t)__popcll(pt_ballot(st == kHit)) < a.reshade_lanes)
                     break;
             }
-            begin_walks();
             if (pt_ballot(st != kFree) == 0ull)
                 break; // pool dry and every lane idle
         }
