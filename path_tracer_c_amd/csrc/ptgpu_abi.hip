@@ -1251,8 +1251,13 @@ int render_common(const ptgpu_scene *s, uint8_t *d_frame, float *d_accum,
             static const uint32_t resolve_lanes = stream_knob("PTGPU_RESOLVE_LANES", 4u);
             q.leaf_lanes = leaf_lanes;
             q.resolve_lanes = resolve_lanes;
-            q.reshade_lanes = kStreamReshadeLanes;
-            q.shade_lanes = kStreamShadeLanes;
+            static const uint32_t shade_lanes = stream_knob("PTGPU_SHADE_LANES", kStreamShadeLanes);
+            static const uint32_t reshade_lanes = stream_knob("PTGPU_RESHADE_LANES", kStreamReshadeLanes);
+            static const uint32_t service_lanes = stream_knob("PTGPU_SERVICE_LANES", kStreamServiceLanes);
+            q.reshade_lanes = reshade_lanes;
+            q.shade_lanes = shade_lanes;
+            if (!p->settle_lanes)
+                q.settle_lanes = service_lanes;
             if (q.stream_walks == 2u) { // (tuning knobs, read per call)
                 auto knob = [](const char *name, uint32_t fallback) {
                     const char *e = std::getenv(name);
