@@ -602,7 +602,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PT_ST
 
     ChunkCursor cursor;
 
-    enum : uint32_t { kFree = 0, kFresh = 1, kWalk = 2, kHit = 3, kParked = 4 };
+    // (numbered so that "waits for a service" is one comparison: >= kFree while the
+    // task pool has chunks left, >= kHit once it is dry)
+    enum : uint32_t { kWalk = 0, kFresh = 1, kFree = 2, kHit = 3, kParked = 4 };
     uint32_t st = kFree;
     uint32_t out_index = 0;
     PathState p;
@@ -679,8 +681,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PT_ST
 #endif
             }
             const unsigned long long walking = pt_ballot(st == kWalk);
-            const unsigned long long waiting =
-                pt_ballot(st == kHit || st == kParked || (st == kFree && !cursor.dry));
+            const unsigned long long waiting = pt_ballot(st >= (cursor.dry ? kHit : kFree));
             full_service = walking == 0ull || (uint32_t)__popcll(waiting) >= a.settle_lanes;
             if (full_service || (uint32_t)__popcll(pt_ballot(st == kHit)) >= a.shade_lanes)
                 break;
