@@ -215,10 +215,11 @@ PT_HD void test_object(const SceneRecords &rec, V3 o, V3 d, uint32_t i,
         const F4 e2 = rec.tri[4 * k + 2];
         found = ray_triangle(o, d, xyz(v0), xyz(e1), xyz(e2), dist);
     }
-    if (found && !(dist >= h.distance && h.distance > 0.0f)) {
-        h.distance = dist;
-        h.object = (int)i;
-    }
+    // (one mask, two selects: as a branch the compiler selected twice, once by the
+    // accept rule inside the branch and once more by `found` around it)
+    const bool take = found && !(dist >= h.distance && h.distance > 0.0f);
+    h.distance = take ? dist : h.distance;
+    h.object = take ? (int)i : h.object;
 }
 
 // The scan of src/ray.c:12-65, every object tested in full.  Right for small
@@ -559,17 +560,13 @@ PT_HD void test_object_unordered(const SceneRecords &rec, V3 o, V3 d, uint32_t i
         const F4 e2 = rec.tri[4 * k + 2];
         found = ray_triangle(o, d, xyz(v0), xyz(e1), xyz(e2), dist);
     }
-    if (found) {
-        if (!(dist > 0.0f)) {
-            if ((int)i > u.deg_idx) {
-                u.deg_idx = (int)i;
-                u.deg_dist = dist;
-            }
-        } else if (dist < u.best || (dist == u.best && (int)i < u.best_idx)) {
-            u.best = dist;
-            u.best_idx = (int)i;
-        }
-    }
+    const bool positive = dist > 0.0f;
+    const bool take_deg = found && !positive && (int)i > u.deg_idx;
+    const bool take_best = found && positive && (dist < u.best || (dist == u.best && (int)i < u.best_idx));
+    u.deg_idx = take_deg ? (int)i : u.deg_idx;
+    u.deg_dist = take_deg ? dist : u.deg_dist;
+    u.best = take_best ? dist : u.best;
+    u.best_idx = take_best ? (int)i : u.best_idx;
 }
 
 // Diagnostic build only (make EXTRA_HIPFLAGS=-DPT_BVH_PROFILE): lane-passes and
