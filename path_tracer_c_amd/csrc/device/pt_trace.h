@@ -59,7 +59,10 @@ PT_HD bool is_triangle_record(const F4 &g) {
 
 // glms_ray_sphere for a unit direction; `r2` is radius*radius.
 // Returns false when there is no root or both roots are behind the origin.
-PT_HD bool ray_sphere(V3 o, V3 d, V3 c, float r2, float &t1, float &t2) {
+// `dist`: the root trace_ray goes on with, `t1 > 0 ? t1 : t2` (src/ray.c:24) -- written
+// only where the roots exist (the caller initialises it), so lanes without a real root
+// need neither root set to anything.
+PT_HD bool ray_sphere(V3 o, V3 d, V3 c, float r2, float &dist) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(PT_FAST_SPHERE) && !defined(PT_X_SPHERE)
     // Tolerance mode: the reference's formulation -- remedy term, roots as q and
     // c/q -- with fused multiply-adds and v_sqrt_f32 / v_rcp_f32 as they come.
@@ -103,8 +106,9 @@ PT_HD bool ray_sphere(V3 o, V3 d, V3 c, float r2, float &t1, float &t2) {
     const float s = __builtin_amdgcn_sqrtf(disc);
     const float q = (b >= 0.0f) ? (b + s) : (b - s);
     const float other = cc * __builtin_amdgcn_rcpf(q);
-    t1 = __builtin_fminf(q, other);
-    t2 = __builtin_fmaxf(q, other);
+    const float t1 = __builtin_fminf(q, other);
+    const float t2 = __builtin_fmaxf(q, other);
+    dist = (t1 > 0.0f) ? t1 : t2;
     return !(t2 < 0.0f);
 #else
     V3 dp = c - o;
@@ -127,8 +131,7 @@ PT_HD bool ray_sphere(V3 o, V3 d, V3 c, float r2, float &t1, float &t2) {
         a = b;
         b = keep;
     }
-    t1 = a;
-    t2 = b;
+    dist = (a > 0.0f) ? a : b;
     return !(a < 0.0f && b < 0.0f);
 #endif
 }
@@ -182,7 +185,6 @@ PT_HD void test_object(const SceneRecords &rec, V3 o, V3 d, uint32_t i,
     float dist = 0.0f;
     bool found;
     if (!is_triangle_record(g)) {
-        float t1 = 0.0f, t2 = 0.0f;
 #if defined(PT_FARREJECT_COUNT) && defined(__HIP_DEVICE_COMPILE__) && !defined(PT_FAST_MATH)
         {
             const V3 dp = xyz(g) - o;
@@ -206,8 +208,7 @@ PT_HD void test_object(const SceneRecords &rec, V3 o, V3 d, uint32_t i,
             }
         }
 #endif
-        found = ray_sphere(o, d, xyz(g), g.w, t1, t2);
-        dist = (t1 > 0.0f) ? t1 : t2; // src/ray.c:24
+        found = ray_sphere(o, d, xyz(g), g.w, dist);
     } else {
         const uint32_t k = rec.link[i];
         const F4 v0 = rec.tri[4 * k + 0];
@@ -550,9 +551,7 @@ PT_HD void test_object_unordered(const SceneRecords &rec, V3 o, V3 d, uint32_t i
     float dist = 0.0f;
     bool found;
     if (!is_triangle_record(g)) {
-        float t1 = 0.0f, t2 = 0.0f;
-        found = ray_sphere(o, d, xyz(g), g.w, t1, t2);
-        dist = (t1 > 0.0f) ? t1 : t2;
+        found = ray_sphere(o, d, xyz(g), g.w, dist);
     } else {
         const uint32_t k = rec.link[i];
         const F4 v0 = rec.tri[4 * k + 0];
