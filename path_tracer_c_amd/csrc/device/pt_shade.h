@@ -30,19 +30,24 @@ __device__ constexpr float kRayOffset = (float)0.001; // src/renderer.c:49,66
 
 // rand_unit_sphere (src/renderer.c:11-19): normalise a point of the cube
 // [-1,1)^3; three draws in x, y, z order.
+//
+// u = (x >> 8) * 2^-24 and u * 2 - 1 (src/renderer.c:12-14 through
+// include/ptgpu_rng.h) are three operations of which two are EXACT -- a 24-bit
+// integer scaled by a power of two, then doubled -- so the value is the one
+// rounding of k * 2^-23 - 1, and one fused multiply-add computes exactly that:
+// the same bits as the sequential form in both builds (and as the oracle's),
+// two instructions less per component.
+__device__ __forceinline__ float unit_cube_component(uint32_t x) {
+    return __builtin_fmaf((float)(x >> 8), 0x1.0p-23f, -1.0f);
+}
 __device__ __forceinline__ V3 rand_unit_sphere(uint32_t &state) {
     state = ptgpu_xorshift32(state);
-    float rx = ptgpu_u32_to_unit(state);
+    const float cx = unit_cube_component(state);
     state = ptgpu_xorshift32(state);
-    float ry = ptgpu_u32_to_unit(state);
+    const float cy = unit_cube_component(state);
     state = ptgpu_xorshift32(state);
-    float rz = ptgpu_u32_to_unit(state);
-#if defined(PT_FUSE)
-    V3 cube = madd(V3{rx, ry, rz}, 2.0f, splat(-1.0f));
-#else
-    V3 cube = V3{rx, ry, rz} * 2.0f - splat(1.0f);
-#endif
-    return normalize(cube);
+    const float cz = unit_cube_component(state);
+    return normalize(V3{cx, cy, cz});
 }
 
 // What one surface interaction decides (src/renderer.c:34-70), given the
