@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <map>
 #include <mutex>
@@ -2651,8 +2652,9 @@ void ptgpu_pool_render_rows(const render_args *queued, size_t n) {
             rows.push_back(&r);
     }
     std::stable_sort(rows.begin(), rows.end(), [](const render_args *a, const render_args *b) {
-        if (a->frame != b->frame) return a->frame < b->frame;
-        if (a->world != b->world) return a->world < b->world;
+        // (std::less: `<` on pointers into different objects is unspecified)
+        if (a->frame != b->frame) return std::less<const void *>()(a->frame, b->frame);
+        if (a->world != b->world) return std::less<const void *>()(a->world, b->world);
         if (a->framew != b->framew) return a->framew < b->framew;
         if (a->frameh != b->frameh) return a->frameh < b->frameh;
         return a->screen_y < b->screen_y;
