@@ -1,5 +1,5 @@
 """Replays one trial of tests/test_parity_gpu.py::test_fast_math_randomised_scenes_are_the_same_picture_in_every_scan_form
-(python tools/repro_fast.py <PT_FUZZ_SEED> <trial>): renders it in every scan form and schedule, exact and tolerance
+(python tests/repro/repro_fast.py <PT_FUZZ_SEED> <trial>): renders it in every scan form and schedule, exact and tolerance
 build, against the oracle, and dumps the scene to gpurun_out/repro_scene.json (tools/scene_json.py reads it back).
 How tests/golden/scenes/screen_hole_r2.json was obtained."""
 import os, sys

@@ -1,5 +1,5 @@
 """Replays one trial of tests/test_parity_gpu.py::test_randomised_rays_through_randomised_scenes_in_every_scan_form
-(python tools/repro_rays.py <PT_FUZZ_SEED> <trial>) and prints the rays on which a scan form differs from the oracle."""
+(python tests/repro/repro_rays.py <PT_FUZZ_SEED> <trial>) and prints the rays on which a scan form differs from the oracle."""
 import sys
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np

@@ -1102,7 +1102,7 @@ def test_randomised_scenes_match_the_oracle(gpu, oracle, branching):
 
 
 def _scene_from_json(gpu, path):
-    """A scene dumped by a fuzz reproduction (tools/repro_fast.py) -> HostScene."""
+    """A scene dumped by a fuzz reproduction (tests/repro/repro_fast.py) -> HostScene."""
     import json
     d = json.loads(Path(path).read_text())
     s = gpu.HostScene()
@@ -1857,6 +1857,50 @@ def test_full_size_config5_rows_against_the_oracle(gpu, torch_cuda, oracle):
     assert np.array_equal(lds[400], ref[400])
 
 
+def _host_threads(limit=16):
+    try:
+        return max(1, min(limit, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(limit, os.cpu_count() or 1))
+
+
+def test_full_size_config2_every_row_against_the_oracle(gpu, torch_cuda, oracle):
+    """BASELINE config 2 at full size, EVERY one of its 1080 rows: the oracle
+    renders the whole 1920x1080 x 256 spp frame on the host's cores (4.7e9 rays,
+    about half a minute on 16 threads) and all 6.2 MB must be equal -- the
+    digests of test_full_size_frames_keep_their_digests pin a frame that was
+    checked on sampled rows; this one checks the frame itself."""
+    c = gpu.CONFIGS[2]
+    w, h = c["width"], c["height"]
+    kw = dict(spp=c["spp"], max_bounces=c["max_bounces"], seed=c["seed"])
+    gpu.host.reset_stats()
+    with gpu.HostScene(c["scene"]) as s, gpu.DeviceScene(s) as d:
+        frame = render_device(gpu, torch_cuda, d, w, h, **kw)
+        gpu_rays = gpu.host.read_stats().rays
+        ref, rays = oracle.render_mt(s, w, h, _host_threads(), **kw)
+    assert rays == gpu_rays                      # the same paths, segment for segment
+    rows = np.flatnonzero((frame != ref).any(axis=(1, 2)))
+    assert rows.size == 0, f"rows that differ: {rows[:10].tolist()} (+{max(0, rows.size - 10)})"
+
+
+def test_full_size_config5_every_row_against_the_oracle_at_16_spp(gpu, torch_cuda, oracle):
+    """BASELINE config 5's 1001 spheres at 1920x1080 through the library's
+    default form (hierarchy, sample queue, resumable walks, shared primary hits)
+    against the oracle's LINEAR scan on every row of the frame (1.1e8 rays x
+    1001 sphere tests on the host's cores) at 16 spp; the configuration's own
+    256 spp: test_full_size_config5_256_spp_against_the_oracle, every eighth row."""
+    c = gpu.CONFIGS[5]
+    w, h = c["width"], c["height"]
+    kw = dict(spp=16, max_bounces=c["max_bounces"], seed=c["seed"])
+    with gpu.HostScene(c["scene"]) as s, gpu.DeviceScene(s) as d:
+        d.tune(w, h, gpu.make_params(**kw))
+        frame = render_device(gpu, torch_cuda, d, w, h, **kw)
+        assert d.scan == "bvh" and d.schedule == "sample-queue"
+        ref, _ = oracle.render_mt(s, w, h, _host_threads(), **kw)
+    bad = np.flatnonzero((frame != ref).any(axis=(1, 2)))
+    assert bad.size == 0, f"rows that differ: {bad[:10].tolist()} (+{max(0, bad.size - 10)})"
+
+
 @pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5"])
 def test_full_size_frames_keep_their_digests(gpu, torch_cuda, name):
     """Every byte of the BASELINE configurations' full-size frames, held to the
@@ -1943,8 +1987,11 @@ def test_full_size_config4_4k_1024_spp_against_the_oracle(gpu, torch_cuda, oracl
         frame = render_device(gpu, torch_cuda, d, w, h, **kw)
         st = gpu.host.read_stats()
         assert st.samples == w * h * c["spp"]
-        for y, row in _oracle_rows(oracle, s, w, h, (3, 1400), **kw).items():
-            assert np.array_equal(frame[y], row), f"row {y}"
+        # every sixteenth row of the 4K frame (135 rows, 4.7e9 rays on the host's cores)
+        ref, _ = oracle.render_mt(s, w, h, _host_threads(), row_begin=3, row_step=16, **kw)
+        rows = np.arange(3, h, 16)
+        bad = rows[(frame[rows] != ref[rows]).any(axis=(1, 2))]
+        assert bad.size == 0, f"rows that differ: {bad[:10].tolist()}"
         for rank in (0, 5):
             sh = tiles.shard_rows(h, 8, rank, 8)
             part = render_device(gpu, torch_cuda, d, w, h, row_begin=sh.row_begin,
@@ -1957,7 +2004,8 @@ def test_full_size_config4_4k_1024_spp_against_the_oracle(gpu, torch_cuda, oracl
 def test_full_size_config5_256_spp_against_the_oracle(gpu, torch_cuda, oracle):
     """BASELINE configs[4] at its real 256 spp: 1001 spheres, 1920x1080, library
     defaults (BVH scan, sample queue, resumable walks, primary hits shared).
-    One sky-heavy and one ground row against the oracle's linear scan."""
+    Every eighth row of the frame (135 rows, 2.2e8 rays) against the oracle's
+    linear scan on the host's cores."""
     c = gpu.CONFIGS[5]
     w, h = c["width"], c["height"]
     assert (w, h, c["spp"]) == (1920, 1080, 256)
@@ -1970,8 +2018,10 @@ def test_full_size_config5_256_spp_against_the_oracle(gpu, torch_cuda, oracle):
         st = gpu.host.read_stats()
         assert st.samples == w * h * c["spp"]
         assert d.scan == "bvh" and d.schedule == "sample-queue"
-        for y, row in _oracle_rows(oracle, s, w, h, (40, 830), **kw).items():
-            assert np.array_equal(frame[y], row), f"row {y}"
+        ref, _ = oracle.render_mt(s, w, h, _host_threads(), row_step=8, **kw)
+    rows = np.arange(0, h, 8)
+    bad = rows[(frame[rows] != ref[rows]).any(axis=(1, 2))]
+    assert bad.size == 0, f"rows that differ: {bad[:10].tolist()}"
 
 
 @pytest.mark.parametrize("workload,scene,w,h,spp", [("c4", 2, 3840, 2160, 1024),
@@ -2446,13 +2496,13 @@ def test_the_references_own_threadpool_drives_render_task(gpu):
     8 worker threads call this library's render_task row by row (rows arrive
     out of order and concurrently: the read-ahead cache and the locks under
     real contention) and the frame equals ptgpu_render_frame's.  In a child
-    process (tools/ref_pool_check.py), which leaves without the reference's
+    process (tests/repro/ref_pool_check.py), which leaves without the reference's
     threadpool_destroy -- that hangs with more than one worker."""
     import sys
     root = Path(__file__).resolve().parent.parent
     if not (root / "oracle" / "_ref" / "libref_host.so").exists():
         pytest.skip("oracle/_ref is not built (no /root/reference at build time)")
-    run = subprocess.run([sys.executable, str(root / "tools" / "ref_pool_check.py")],
+    run = subprocess.run([sys.executable, str(root / "tests" / "repro" / "ref_pool_check.py")],
                          capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout + run.stderr
     assert run.stdout.count("frame equal to ptgpu_render_frame: True") == 2, run.stdout
